@@ -1,0 +1,181 @@
+#!/usr/bin/env python
+"""Generate tests/golden/*.npz by running the REFERENCE's own hot-path functions.
+
+Run in the build container only (needs /root/reference):
+
+    python tests/golden/make_golden.py
+
+What is executed: /root/reference/tetrad/src/resolve_quartets.py, loaded by file
+path, unmodified.  Its two top-level imports that are not installed here are
+satisfied as SURVEY.md section 8c describes: ``numba.njit`` becomes the identity
+decorator (the two jitted functions are pure integer counting loops, so running
+them interpreted is exact), ``h5py`` is an empty module (only the outer HDF5
+wrapper :33-35 uses it and it is not called).  ``np.uint32(-1)`` at :58 raises
+under NumPy 2.x where numba wraps to 4294967295, so the loaded module sees a
+NumPy proxy whose ``uint32`` wraps like numba's.  The SVD / rank arithmetic is
+plain ``numpy.linalg`` in the reference as well.
+
+What is stored: inputs (tmparr, tmpmap, quartets) and the reference's outputs
+(rstat, rscor from new_infer_resolved_quartets; cmats from the two count
+kernels called exactly as :221/:223 call them; singular values from the same
+numpy call as :242).  Data only -- no reference source text.
+
+Zero-data quartets: the reference's topology there is an unseeded
+``np.random.randint(3)`` (:231); those rows are recorded in ``zero_data`` and
+their topology is not part of the contract.
+"""
+from __future__ import annotations
+
+import importlib.util
+import sys
+import types
+from pathlib import Path
+
+import numpy as np
+
+REPO = Path(__file__).resolve().parents[2]
+sys.path.insert(0, str(REPO))
+from tetrad_amd import synth  # noqa: E402
+
+REF = Path("/root/reference/tetrad/src/resolve_quartets.py")
+OUT = Path(__file__).resolve().parent
+
+
+def load_reference():
+    numba = types.ModuleType("numba")
+    numba.njit = lambda f=None, **k: f if f is not None else (lambda g: g)
+    sys.modules.setdefault("numba", numba)
+    sys.modules.setdefault("h5py", types.ModuleType("h5py"))
+    spec = importlib.util.spec_from_file_location("ref_resolve_quartets", REF)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+
+    class WrapU32(np.uint32):           # still a valid dtype (-> uint32)
+        def __new__(cls, v=0):
+            return np.uint32(int(v) & 0xFFFFFFFF)
+
+    class NPProxy:
+        uint32 = WrapU32
+
+        def __getattr__(self, name):
+            return getattr(np, name)
+
+    mod.np = NPProxy()
+    return mod
+
+
+def run_reference(ref, tmparr, tmpmap, quartets, subsample, with_cmats=True):
+    np.random.seed(0)  # only affects the zero-data randint, which is not contractual
+    q, rstat, rscor = ref.new_infer_resolved_quartets(tmparr, tmpmap, quartets, subsample)
+    out = dict(rstat=rstat, rscor=rscor)
+    if with_cmats:
+        Q = quartets.shape[0]
+        cmats = np.zeros((Q, 3, 16, 16), np.uint32)
+        svds = np.zeros((Q, 3, 16), np.float64)
+        for i in range(Q):
+            seqs = tmparr[quartets[i], :]
+            nmask0 = np.sum(seqs >= 78, axis=0)
+            nmask1 = np.sum(seqs == seqs[0], axis=0) == 4
+            fn = ref.subsample_chunk_to_matrices if subsample else ref.full_chunk_to_matrices
+            cmats[i] = fn(seqs, tmpmap[:, 0], nmask0 + nmask1)
+            if cmats[i, 0].sum():
+                for t in range(3):
+                    svds[i, t] = np.linalg.svd(cmats[i, t].astype(np.float64))[1]
+        out["cmats"] = cmats
+        out["svds"] = svds
+    out["zero_data"] = (rstat[:, 1] == 0)
+    return out
+
+
+def save(name, tmparr, tmpmap, quartets, ref, with_cmats=True):
+    blob = dict(tmparr=tmparr, tmpmap=tmpmap, quartets=quartets,
+                numpy_version=np.array(np.__version__))
+    for sub in (False, True):
+        res = run_reference(ref, tmparr, tmpmap, quartets, sub, with_cmats)
+        tag = "sub" if sub else "full"
+        for k, v in res.items():
+            blob[f"{tag}_{k}"] = v
+    np.savez_compressed(OUT / f"{name}.npz", **blob)
+    print(f"wrote {name}.npz  T={tmparr.shape[0]} S={tmparr.shape[1]} Q={quartets.shape[0]}")
+
+
+def loci_map(S, rng, mean=4):
+    lens = 1 + rng.poisson(mean, size=S)
+    loc = np.repeat(np.arange(S, dtype=np.uint32), lens)[:S]
+    tmap = np.zeros((S, 2), np.uint32)
+    tmap[:, 0] = loc
+    tmap[:, 1] = np.arange(S)
+    return tmap
+
+
+def main():
+    ref = load_reference()
+
+    # (1) dense uniform-random data, T=8, S=400 (S not a multiple of 64), all 70 quartets
+    rng = np.random.default_rng(1)
+    arr = rng.integers(0, 4, size=(8, 400), dtype=np.uint8)
+    arr[rng.random(arr.shape) < 0.1] = 78
+    save("dense_T8_S400", arr, loci_map(400, rng), synth.all_quartets(8), ref)
+
+    # (2) tree-like simulated data, T=12, S=2000, all 495 quartets
+    arr, tmap = synth.simulate_tmparr(12, 2000, seed=2)
+    save("tree_T12_S2000", arr, tmap, synth.all_quartets(12), ref)
+
+    # (3) sparse / degenerate: few informative sites, low substitution rate
+    arr, tmap = synth.simulate_tmparr(10, 257, seed=3, p=0.01, missing=0.3)
+    save("sparse_T10_S257", arr, tmap, synth.all_quartets(10), ref)
+
+    # (4)+(5) zero-data quartets and an all-missing taxon
+    rng = np.random.default_rng(4)
+    arr = rng.integers(0, 4, size=(7, 130), dtype=np.uint8)
+    arr[3, :] = 78                       # taxon 3 entirely missing
+    arr[5, :] = arr[4, :]                # taxa 4,5 identical
+    arr[6, :] = arr[4, :]                # ... and 6: quartets within {4,5,6,x} still vary via x
+    arr[0, :] = 2                        # taxon 0 constant
+    save("edge_T7_S130", arr, loci_map(130, rng), synth.all_quartets(7), ref)
+
+    # (6) locus runs whose leading sites are all masked (subsample carry), long loci,
+    #     plus a run crossing the 64- and 1024-site boundaries
+    rng = np.random.default_rng(6)
+    S = 2500
+    arr = rng.integers(0, 4, size=(6, S), dtype=np.uint8)
+    arr[rng.random(arr.shape) < 0.45] = 78
+    tmap = loci_map(S, rng, mean=40)
+    save("carry_T6_S2500", arr, tmap, synth.all_quartets(6), ref)
+
+    # (7) tiny S (shorter than one wavefront) and S == 1
+    rng = np.random.default_rng(7)
+    arr = rng.integers(0, 4, size=(5, 37), dtype=np.uint8)
+    save("tiny_T5_S37", arr, loci_map(37, rng, mean=2), synth.all_quartets(5), ref)
+    arr = np.array([[0], [1], [0], [1], [2]], dtype=np.uint8)
+    save("one_site_T5_S1", arr, loci_map(1, rng), synth.all_quartets(5), ref)
+
+    # (8) low-rank: only two alleles segregating -> rank << 10 (minrank < 10 branch)
+    rng = np.random.default_rng(8)
+    arr = (rng.random((9, 700)) < 0.5).astype(np.uint8) * 2     # only A / G
+    arr[rng.random(arr.shape) < 0.05] = 78
+    save("lowrank_T9_S700", arr, loci_map(700, rng), synth.all_quartets(9), ref)
+
+    # (9) config c1: 16 taxa, 5k SNPs, all 1820 quartets (BASELINE.json configs[0]).
+    arr, tmap, qrts = synth.make_config("c1")
+    save("c1_T16_S5000", arr, tmap, qrts, ref, with_cmats=False)
+
+    # (10) slices of c2 / c3 shaped inputs are regenerated from the seed on the fly by
+    #      the tests (inputs are deterministic); only the reference outputs for a few
+    #      quartets are stored here.
+    for cfg, nq in (("c2", 24), ("c3", 12)):
+        T, S, _ = synth.CONFIGS[cfg]
+        arr, tmap = synth.simulate_tmparr(T, S, synth.CONFIG_SEEDS[cfg])
+        qrts = synth.random_quartets(T, nq, seed=777)
+        blob = dict(quartets=qrts, config=np.array(cfg), numpy_version=np.array(np.__version__))
+        for sub in (False, True):
+            res = run_reference(ref, arr, tmap, qrts, sub, with_cmats=True)
+            tag = "sub" if sub else "full"
+            for k, v in res.items():
+                blob[f"{tag}_{k}"] = v
+        np.savez_compressed(OUT / f"{cfg}_slice.npz", **blob)
+        print(f"wrote {cfg}_slice.npz")
+
+
+if __name__ == "__main__":
+    main()

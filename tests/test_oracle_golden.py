@@ -1,0 +1,68 @@
+"""Pin the oracle (oracle/) against outputs of the reference's own functions
+(tests/golden/*.npz, made by tests/golden/make_golden.py).  CPU only."""
+import numpy as np
+import pytest
+
+from conftest import GOLDEN_FULL_CASES, load_golden
+
+
+@pytest.mark.parametrize("case", GOLDEN_FULL_CASES)
+@pytest.mark.parametrize("mode", ["full", "sub"])
+def test_oracle_matches_reference(oracle, case, mode):
+    g = load_golden(case)
+    sub = mode == "sub"
+    q, rstat, rscor, dbg = oracle.new_infer_resolved_quartets(
+        g["tmparr"], g["tmpmap"], g["quartets"], sub, debug=True)
+    zero = g[f"{mode}_zero_data"]
+    # integer outputs: bit exact
+    np.testing.assert_array_equal(q, g["quartets"])
+    np.testing.assert_array_equal(dbg["cmats"], g[f"{mode}_cmats"])
+    np.testing.assert_array_equal(rstat[:, 1], g[f"{mode}_rstat"][:, 1])
+    np.testing.assert_array_equal((dbg["flags"] & 1).astype(bool), zero)
+    # same numpy.linalg calls as the reference => bit-identical here
+    np.testing.assert_array_equal(rscor, g[f"{mode}_rscor"])
+    np.testing.assert_array_equal(dbg["svds"][~zero], g[f"{mode}_svds"][~zero])
+    # topology: everywhere except the reference's unseeded random pick
+    np.testing.assert_array_equal(rstat[~zero, 0], g[f"{mode}_rstat"][~zero, 0])
+
+
+@pytest.mark.parametrize("mode", ["full", "sub"])
+def test_oracle_c1_full_run(oracle, mode):
+    """BASELINE.json configs[0]: 16 taxa, 5k SNPs, all 1820 quartets."""
+    g = load_golden("c1_T16_S5000")
+    q, rstat, rscor = oracle.new_infer_resolved_quartets(
+        g["tmparr"], g["tmpmap"], g["quartets"], mode == "sub")
+    assert not g[f"{mode}_zero_data"].any()
+    np.testing.assert_array_equal(rstat, g[f"{mode}_rstat"])
+    np.testing.assert_array_equal(rscor, g[f"{mode}_rscor"])
+
+
+def test_numpy_spelled_out_variant_matches(oracle):
+    g = load_golden("dense_T8_S400")
+    for sub in (False, True):
+        a = oracle.new_infer_resolved_quartets(g["tmparr"], g["tmpmap"], g["quartets"], sub)
+        b = oracle.new_infer_resolved_quartets_numpy(g["tmparr"], g["tmpmap"], g["quartets"], sub)
+        for x, y in zip(a, b):
+            np.testing.assert_array_equal(x, y)
+
+
+@pytest.mark.parametrize("case", ["tiny_T5_S37", "edge_T7_S130", "carry_T6_S2500"])
+def test_c_count_kernels_match_python_loops(oracle, case):
+    g = load_golden(case)
+    arr, loc = g["tmparr"], np.ascontiguousarray(g["tmpmap"][:, 0])
+    for qd in g["quartets"][:6]:
+        seqs = arr[qd, :]
+        mask = np.sum(seqs >= 78, axis=0) + (np.sum(seqs == seqs[0], axis=0) == 4)
+        for sub in (False, True):
+            fn = oracle.subsample_chunk_to_matrices if sub else oracle.full_chunk_to_matrices
+            np.testing.assert_array_equal(
+                fn(seqs, loc, mask), oracle.chunk_to_matrices_py(seqs, loc, mask, sub))
+
+
+def test_flattenings_are_tensor_transposes(oracle):
+    """M1 = C.transpose(0,2,1,3), M2 = C.transpose(0,3,1,2)."""
+    g = load_golden("tree_T12_S2000")
+    cm = g["full_cmats"][:50]
+    C = cm[:, 0].reshape(-1, 4, 4, 4, 4)
+    np.testing.assert_array_equal(cm[:, 1], C.transpose(0, 1, 3, 2, 4).reshape(-1, 16, 16))
+    np.testing.assert_array_equal(cm[:, 2], C.transpose(0, 1, 4, 2, 3).reshape(-1, 16, 16))

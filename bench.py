@@ -1,0 +1,204 @@
+#!/usr/bin/env python
+"""bench.py -- resolved quartets/s of the per-quartet hot path on N MI355X.
+
+One "step" = one pass of the hot path (tq_resolve_dev: site scan -> 16x16 count matrices ->
+3 singular-value decompositions -> scores/topology) over one batch of synthetic quartets that
+is already resident in HBM, plus -- for N > 1 -- the RCCL all-gather of the result records.
+
+Workload at N=1: BASELINE.json configs[2] ("c3"): 128 taxa, 50k SNPs, 1e6 random quartets,
+subsample_snps=True (the reference's default, resolve_quartets.py:21).  Weak scaling: every
+rank resolves its own contiguous 1e6-quartet shard of an N x 1e6 global sample.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (HIP-event
+kernel time on the launch stream vs algorithmic bytes, SURVEY.md 8d: A = 4*S + 48 B/quartet)
+and `cpu_baseline` (the oracle -- a port of the reference worker -- timed on host cores).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+REPO = Path(__file__).resolve().parent
+sys.path.insert(0, str(REPO))
+
+HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def _cpu_worker(args):
+    """cpu_baseline leg: the oracle (port of resolve_quartets.py:191-265) on one host core."""
+    os.environ["OPENBLAS_NUM_THREADS"] = "1"
+    from oracle import oracle as orc
+    tmparr, tmpmap, quartets, sub = args
+    try:
+        from threadpoolctl import threadpool_limits
+        ctx = threadpool_limits(1)
+    except Exception:  # pragma: no cover
+        ctx = None
+    t0 = time.perf_counter()
+    _, rstat, rscor = orc.new_infer_resolved_quartets(tmparr, tmpmap, quartets, sub)
+    dt = time.perf_counter() - t0
+    return dt, rstat, rscor
+
+
+def cpu_baseline(tmparr, tmpmap, quartets, sub, gpu_rstat, gpu_rscor, budget_s=15.0):
+    import multiprocessing as mp
+    from oracle import oracle as orc
+    orc.build()
+    cores = max(1, min(16, len(os.sched_getaffinity(0))))
+    # calibrate on one core, then size the sample for ~budget_s of wall time on all cores
+    dt, _, _ = _cpu_worker((tmparr, tmpmap, quartets[:300], sub))
+    per_core = 300 / dt
+    n = int(min(len(quartets), max(cores * 200, per_core * cores * budget_s)))
+    chunks = np.array_split(np.arange(n), cores)
+    t0 = time.perf_counter()
+    with mp.get_context("fork").Pool(cores) as pool:
+        res = pool.map(_cpu_worker, [(tmparr, tmpmap, quartets[c], sub) for c in chunks])
+    wall = time.perf_counter() - t0
+    rstat = np.concatenate([r[1] for r in res])
+    rscor = np.concatenate([r[2] for r in res])
+    # the oracle doubles as the checker on this sample
+    parity = dict(
+        n=n,
+        nsnps_equal=bool(np.array_equal(rstat[:, 1], gpu_rstat[:n, 1])),
+        topology_equal=bool(np.array_equal(rstat[:, 0], gpu_rstat[:n, 0])),
+        score_max_rel_err=float(np.max(np.abs(rscor - gpu_rscor[:n]) / np.abs(rscor))),
+    )
+    return dict(value=n / wall, unit="quartets/s", cores=cores, kind="port",
+                sample=f"first {n} quartets of the same batch, {cores} processes x 1 thread, "
+                       f"oracle.new_infer_resolved_quartets (C count loop + numpy.linalg svd/matrix_rank)",
+                per_core=per_core), parity
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--config", default="c3", choices=["c2", "c3", "c4"])
+    ap.add_argument("--quartets", type=int, default=0, help="quartets per GPU (0 = config default)")
+    ap.add_argument("--full", action="store_true", help="subsample_snps=False")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--nrep", type=int, default=0)
+    ap.add_argument("--waves-per-cu", type=int, default=0)
+    args = ap.parse_args()
+
+    import torch
+    from tetrad_amd import synth
+    from tetrad_amd.engine import QuartetEngine
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+
+    T, S, qdef = synth.CONFIGS[args.config]
+    sub = not args.full
+    tmparr, tmpmap = synth.simulate_tmparr(T, S, synth.CONFIG_SEEDS[args.config])
+    Q = args.quartets or qdef or int(synth.comb(T, 4))
+    if qdef is None and not args.quartets:
+        quartets = synth.all_quartets(T)
+    else:
+        # one global sample of world*Q quartets, rank r owns the contiguous slice [r*Q, (r+1)*Q)
+        idx = np.random.default_rng(synth.CONFIG_SEEDS[args.config] + 1000).choice(
+            synth.comb(T, 4), size=world * Q, replace=False)
+        quartets = synth.unrank_quartets(idx[rank * Q:(rank + 1) * Q], T)
+
+    eng = QuartetEngine(local_rank)
+    if args.nrep:
+        eng.set_option("nrep", args.nrep)
+    if args.waves_per_cu:
+        eng.set_option("waves_per_cu", args.waves_per_cu)
+    eng.set_data(tmparr, tmpmap)
+
+    d_q = torch.from_numpy(quartets.astype(np.int32)).to(dev)
+    d_rstat = torch.zeros((Q, 2), dtype=torch.int32, device=dev)
+    d_rscor = torch.zeros((Q, 3), dtype=torch.float64, device=dev)
+    d_flags = torch.zeros(Q, dtype=torch.uint8, device=dev)
+    if world > 1:
+        g_rstat = torch.zeros((world * Q, 2), dtype=torch.int32, device=dev)
+        g_rscor = torch.zeros((world * Q, 3), dtype=torch.float64, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step():
+        eng.resolve_dev(d_q.data_ptr(), Q, sub, d_rstat.data_ptr(), d_rscor.data_ptr(),
+                        d_flags.data_ptr(), stream)
+        if world > 1:
+            dist.all_gather_into_tensor(g_rstat, d_rstat)
+            dist.all_gather_into_tensor(g_rscor, d_rscor)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    eng.timing_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    kernel_ms, launches = eng.timing_read()
+    eng.timing_enable(False)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    rstat = d_rstat.cpu().numpy().astype(np.uint32)
+    rscor = d_rscor.cpu().numpy()
+    flags = d_flags.cpu().numpy()
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        value = world * Q * args.steps / elapsed
+        A = 4 * S + 48                                   # algorithmic bytes per quartet
+        bytes_per_launch = Q * A + 4 * S
+        avg_kernel_s = kernel_ms / max(1, launches) / 1e3
+        achieved = bytes_per_launch / avg_kernel_s / 1e9
+        traffic = None
+        tf = REPO / "profiles" / f"traffic_{args.config}_{'sub' if sub else 'full'}.json"
+        if tf.exists():
+            traffic = json.loads(tf.read_text()).get("hbm_bytes_per_launch")
+        line = {
+            "metric": "resolved quartets/sec (whole node)", "value": value, "unit": "quartets/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u8 scan / u32 counts / f64 SVD", "data": "synthetic",
+            "config": {"workload": f"{args.config}: {T} taxa x {S} SNPs, {Q} random quartets per GPU, "
+                                   f"subsample_snps={sub}", "quartets_per_gpu": Q, "taxa": T, "snps": S,
+                       "subsample_snps": sub, "parallelism": f"quartet-sharded x{world} + all-gather"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel": "tq_resolve_kernel", "kernel_ms": kernel_ms / max(1, launches),
+                         "algorithmic_bytes_per_launch": bytes_per_launch},
+            "flags": {"zero_data": int((flags & 1).sum()), "degenerate": int(((flags & 2) > 0).sum())},
+        }
+        if not args.no_cpu:
+            cb, parity = cpu_baseline(tmparr, tmpmap, quartets, sub, rstat, rscor)
+            line["cpu_baseline"] = cb
+            line["parity_on_cpu_sample"] = parity
+            line["gpu_over_cpu"] = value / cb["value"]
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,133 @@
+/*
+ * tetrad_hip.h -- C ABI of the MI355X (gfx950) quartet-invariant engine.
+ *
+ * This is the drop-in boundary for tetrad's per-chunk worker.  Each entry point
+ * cites the reference interface it replaces (paths relative to the reference
+ * checkout).  The reference is pure Python, so "the FFI a maintainer would
+ * bind" is ctypes; the binding is shown in INTEGRATION.md and shipped as
+ * tetrad_amd/_lib.py.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes only.
+ *   - every function returns TQ_OK (0) or a negative TQ_ERR_* code; it never
+ *     throws and never aborts.  tq_last_error() returns a human-readable
+ *     message for the last failure on that context (or the last failure of
+ *     tq_create when ctx is NULL).
+ *   - one context per (process, device).  A context is not thread-safe;
+ *     distinct contexts are independent.  The library keeps no host pointer
+ *     after a call returns.
+ *   - host-buffer entry points (tq_set_data, tq_resolve, tq_resolve_debug)
+ *     are synchronous.  *_dev entry points take device pointers, enqueue on
+ *     the given HIP stream and return without synchronising.
+ */
+#ifndef TETRAD_HIP_H
+#define TETRAD_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct tq_ctx tq_ctx;
+
+enum {
+    TQ_OK = 0,
+    TQ_ERR_INVALID_ARG = -1,   /* NULL pointer, negative size, taxon index >= T ... */
+    TQ_ERR_NO_DEVICE = -2,     /* no HIP device / device is not usable             */
+    TQ_ERR_HIP = -3,           /* a HIP runtime call failed (see tq_last_error)    */
+    TQ_ERR_NO_DATA = -4,       /* tq_resolve* before tq_set_data                   */
+    TQ_ERR_LOCUS_ORDER = -5,   /* subsample requested but a locus id re-appears
+                                  after its run ended (see tq_set_data)            */
+    TQ_ERR_OOM = -6
+};
+
+/* per-quartet flag bits written by tq_resolve* */
+enum {
+    TQ_FLAG_ZERO_DATA = 1,     /* no site counted: scores are 0.001, topology 0.
+                                  (reference: unseeded np.random.randint(3),
+                                  resolve_quartets.py:230-232)                      */
+    TQ_FLAG_DEGENERATE = 2,    /* two lowest scores within 1e-9 * sigma_max: argmin is
+                                  decided by SVD rounding noise in any implementation */
+    TQ_FLAG_BAD_INDEX = 4      /* a taxon index was >= T; row treated as zero-data   */
+};
+
+/* Create / destroy a context bound to HIP device `device_id`.
+ * Replaces: the per-engine process state of the reference (an ipyparallel
+ * engine that re-opens the HDF5 file on every call, resolve_quartets.py:33-35). */
+int tq_create(tq_ctx **out, int device_id);
+void tq_destroy(tq_ctx *ctx);
+const char *tq_last_error(const tq_ctx *ctx);
+
+/* Upload one replicate's genotype matrix and locus column (H2D once per
+ * replicate, not once per chunk).
+ * Replaces: `tmparr = io5["tmparr"][:]; tmpmap = io5["tmpmap"][:]`
+ *           (resolve_quartets.py:33-35) and the `tmpmap[:, 0]` argument of
+ *           resolve_quartets.py:221,223.
+ *   tmparr  u8 [T,S] row-major; 0..3 = A,C,G,T; anything > 3 (78 = N) is missing
+ *   locus   u32, element i at locus[i * locus_stride]  (pass tmpmap and stride 2
+ *           to use tmpmap[:,0] without a copy)
+ * Subsample mode requires every locus id to occupy one contiguous run of sites
+ * (always true for the reference's writers: write_database.py:138-149,
+ * jit/resample.py:58) and no id equal to 0xFFFFFFFF; otherwise tq_resolve*
+ * with subsample != 0 returns TQ_ERR_LOCUS_ORDER.                                  */
+int tq_set_data(tq_ctx *ctx, const uint8_t *tmparr, int64_t T, int64_t S,
+                const uint32_t *locus, int64_t locus_stride);
+
+/* Resolve Q quartets (host buffers, synchronous).
+ * Replaces: new_infer_resolved_quartets(tmparr, tmpmap, quartets, subsample_snps)
+ *           (resolve_quartets.py:191-265), which returns (quartets, rstat, rscor).
+ *   quartets u32 [Q,4]  taxon indices (returned unchanged by the reference, :265)
+ *   rstat    u32 [Q,2]  out: [:,0] topology 0/1/2 (argmin of scores, :251),
+ *                            [:,1] number of counted sites (:226,:264)
+ *   rscor    f64 [Q,3]  out: invariant score of the three flattenings (:246-248)
+ *   flags    u8  [Q]    out, may be NULL: TQ_FLAG_* bits                           */
+int tq_resolve(tq_ctx *ctx, const uint32_t *quartets, int64_t Q, int subsample,
+               uint32_t *rstat, double *rscor, uint8_t *flags);
+
+/* Same, device pointers, asynchronous on `stream` (a hipStream_t; NULL = the
+ * default stream).  This is what bench.py times (inputs resident in HBM).        */
+int tq_resolve_dev(tq_ctx *ctx, const uint32_t *d_quartets, int64_t Q, int subsample,
+                   uint32_t *d_rstat, double *d_rscor, uint8_t *d_flags, void *stream);
+
+/* Full-mode quartet generation on the device: resolves the quartets whose
+ * lexicographic ranks are [first_rank, first_rank+Q) among C(T,4), i.e. what
+ * islice(combinations(range(T),4), start, end) yields (combinations.py:40-55),
+ * without any quartet H2D.  d_quartets (u32[Q,4], may be NULL) receives them.     */
+int tq_resolve_range_dev(tq_ctx *ctx, uint64_t first_rank, int64_t Q, int subsample,
+                         uint32_t *d_quartets, uint32_t *d_rstat, double *d_rscor,
+                         uint8_t *d_flags, void *stream);
+
+/* Random-mode quartet generation on the device: unranks host-sampled
+ * lexicographic ranks (combinations.py:94-114) into d_quartets.                    */
+int tq_unrank_dev(tq_ctx *ctx, const uint64_t *d_ranks, int64_t Q, uint32_t *d_quartets,
+                  void *stream);
+
+/* Kernel-level outputs for parity tests (host buffers, synchronous); any of the
+ * debug pointers may be NULL.
+ * Replaces: subsample_chunk_to_matrices / full_chunk_to_matrices
+ *           (resolve_quartets.py:42-104) -> cmats u32[Q,3,16,16];
+ *           np.linalg.svd(...)[1] (:242) -> svds f64[Q,3,16] (descending);
+ *           np.linalg.matrix_rank (:243) -> ranks i32[Q,3].                        */
+int tq_resolve_debug(tq_ctx *ctx, const uint32_t *quartets, int64_t Q, int subsample,
+                     uint32_t *rstat, double *rscor, uint8_t *flags,
+                     uint32_t *cmats, double *svds, int32_t *ranks);
+
+/* HIP-event timing of the resolve kernel, on the stream it was launched on.
+ * tq_timing_enable(ctx, 1) makes every subsequent resolve launch record a
+ * start/stop event pair; tq_timing_read synchronises those events, returns the
+ * summed kernel milliseconds and launch count since the last reset, and resets. */
+int tq_timing_enable(tq_ctx *ctx, int on);
+int tq_timing_read(tq_ctx *ctx, double *kernel_ms, int64_t *launches);
+
+/* Tuning knobs (0 = library default).  Returns the value in effect. */
+int tq_set_option(tq_ctx *ctx, const char *name, int64_t value);
+
+/* Device facts used by bench.py: writes CU count, wave slots used by the resolve
+ * kernel per CU and the padded row pitch in bytes.                                 */
+int tq_device_info(tq_ctx *ctx, int32_t *num_cu, int32_t *waves_per_cu, int64_t *row_pitch);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TETRAD_HIP_H */

@@ -1,0 +1,238 @@
+"""GPU parity tests proper: the HIP path, called through the C ABI, against the golden
+vectors (reference outputs) and against the oracle on seeded inputs.
+
+Bars: bit-exact for integer outputs (count matrices, nsnps, rank, topology on
+non-degenerate quartets); singular values and scores within
+|x - ref| <= 1e-6*|ref| + 1e-12*sigma_max  (north_star: 1e-6 relative; the absolute term
+only covers values that are numerically zero, where a relative error is undefined).
+"""
+import numpy as np
+import pytest
+
+from conftest import GOLDEN_FULL_CASES, load_golden
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-6
+ATOL_REL_SMAX = 1e-12
+
+
+@pytest.fixture(scope="module")
+def engine():
+    from tetrad_amd.engine import QuartetEngine
+    eng = QuartetEngine(0)
+    yield eng
+    eng.close()
+
+
+def assert_close(x, ref, smax, what):
+    tol = RTOL * np.abs(ref) + ATOL_REL_SMAX * smax
+    bad = np.abs(x - ref) > tol
+    assert not bad.any(), f"{what}: {bad.sum()} values out of tolerance, worst {np.abs(x - ref).max()}"
+
+
+def check_against(g, mode, rstat, rscor, flags, dbg):
+    zero = g[f"{mode}_zero_data"]
+    ref_rstat, ref_rscor = g[f"{mode}_rstat"], g[f"{mode}_rscor"]
+    np.testing.assert_array_equal(rstat[:, 1], ref_rstat[:, 1])
+    np.testing.assert_array_equal((flags & 1).astype(bool), zero)
+    np.testing.assert_array_equal(rscor[zero], ref_rscor[zero])            # 0.001 rows
+    assert (rstat[zero, 0] == 0).all()
+    if f"{mode}_cmats" in g:
+        np.testing.assert_array_equal(dbg["cmats"], g[f"{mode}_cmats"])
+        ref_sv = g[f"{mode}_svds"]
+        smax = ref_sv.max(axis=(1, 2))
+        assert_close(dbg["svds"][~zero], ref_sv[~zero], smax[~zero, None, None], "singular values")
+        ref_rank = (ref_sv > ref_sv.max(axis=2, keepdims=True) * 16 * np.finfo(float).eps).sum(axis=2)
+        np.testing.assert_array_equal(dbg["ranks"][~zero], ref_rank[~zero])
+    else:
+        smax = np.full(len(rstat), np.abs(ref_rscor).max())
+    assert_close(rscor[~zero], ref_rscor[~zero], smax[~zero, None], "scores")
+    # topology: bit exact wherever the argmin is not decided by SVD rounding noise
+    s = np.sort(ref_rscor, axis=1)
+    ref_deg = (s[:, 1] - s[:, 0]) <= 1e-9 * smax
+    ok = ~zero & ~ref_deg & ((flags & 2) == 0)
+    np.testing.assert_array_equal(rstat[ok, 0], ref_rstat[ok, 0])
+    return int(ok.sum()), int((~zero & ~ok).sum())
+
+
+@pytest.mark.parametrize("case", GOLDEN_FULL_CASES)
+@pytest.mark.parametrize("mode", ["full", "sub"])
+def test_golden_cases(engine, case, mode):
+    g = load_golden(case)
+    engine.set_data(g["tmparr"], g["tmpmap"])
+    rstat, rscor, flags, dbg = engine.resolve(g["quartets"], mode == "sub", debug=True)
+    check_against(g, mode, rstat, rscor, flags, dbg)
+
+
+@pytest.mark.parametrize("mode", ["full", "sub"])
+def test_c1_full_run(engine, mode):
+    """BASELINE.json configs[0]: 16 taxa / 5k SNPs / all 1820 quartets vs the reference."""
+    g = load_golden("c1_T16_S5000")
+    engine.set_data(g["tmparr"], g["tmpmap"])
+    rstat, rscor, flags = engine.resolve(g["quartets"], mode == "sub")
+    nok, ndeg = check_against(g, mode, rstat, rscor, flags, None)
+    assert ndeg == 0 and nok == 1820
+    np.testing.assert_array_equal(rstat, g[f"{mode}_rstat"])
+
+
+@pytest.mark.parametrize("cfg", ["c2", "c3"])
+def test_config_slices(engine, cfg):
+    """Reference outputs for a few quartets of the c2 / c3 benchmark inputs (regenerated from the seed)."""
+    from tetrad_amd import synth
+    g = load_golden(f"{cfg}_slice")
+    T, S, _ = synth.CONFIGS[cfg]
+    tmparr, tmpmap = synth.simulate_tmparr(T, S, synth.CONFIG_SEEDS[cfg])
+    engine.set_data(tmparr, tmpmap)
+    for mode in ("full", "sub"):
+        rstat, rscor, flags, dbg = engine.resolve(g["quartets"], mode == "sub", debug=True)
+        nok, ndeg = check_against(g, mode, rstat, rscor, flags, dbg)
+        assert ndeg == 0
+
+
+@pytest.mark.parametrize("seed,T,S,missing,p", [(21, 20, 3000, 0.1, 0.05), (22, 9, 4097, 0.5, 0.02),
+                                                 (23, 30, 2048, 0.0, 0.2), (24, 6, 65, 0.2, 0.1)])
+def test_seeded_vs_oracle(engine, oracle, seed, T, S, missing, p):
+    from tetrad_amd import synth
+    tmparr, tmpmap = synth.simulate_tmparr(T, S, seed, p=p, missing=missing)
+    rng = np.random.default_rng(seed)
+    quartets = synth.all_quartets(T)
+    quartets = quartets[rng.permutation(len(quartets))[:400]]
+    engine.set_data(tmparr, tmpmap)
+    for sub in (False, True):
+        rstat, rscor, flags, dbg = engine.resolve(quartets, sub, debug=True)
+        _, o_rstat, o_rscor, o = oracle.new_infer_resolved_quartets(tmparr, tmpmap, quartets, sub, debug=True)
+        np.testing.assert_array_equal(dbg["cmats"], o["cmats"])
+        np.testing.assert_array_equal(rstat[:, 1], o_rstat[:, 1])
+        zero = (o["flags"] & 1).astype(bool)
+        np.testing.assert_array_equal((flags & 1).astype(bool), zero)
+        smax = np.maximum(o["svds"].max(axis=(1, 2)), 1e-300)
+        assert_close(dbg["svds"][~zero], o["svds"][~zero], smax[~zero, None, None], "singular values")
+        assert_close(rscor, o_rscor, smax[:, None], "scores")
+        np.testing.assert_array_equal(dbg["ranks"][~zero], o["rank"][~zero])
+        ok = ((flags | o["flags"]) & 3) == 0
+        np.testing.assert_array_equal(rstat[ok, 0], o_rstat[ok, 0])
+
+
+@pytest.mark.parametrize("nrep", [1, 2, 4, 8, 16, 32])
+def test_histogram_replica_counts_agree(engine, nrep):
+    g = load_golden("tree_T12_S2000")
+    engine.set_data(g["tmparr"], g["tmpmap"])
+    engine.set_option("nrep", nrep)
+    try:
+        for mode in ("full", "sub"):
+            _, _, _, dbg = engine.resolve(g["quartets"][:97], mode == "sub", debug=True)
+            np.testing.assert_array_equal(dbg["cmats"], g[f"{mode}_cmats"][:97])
+    finally:
+        engine.set_option("nrep", 0)
+
+
+def test_locus_carry_across_lane_and_tile_boundaries(engine, oracle):
+    """Subsample carry: loci longer than a lane's 32 sites and than a 2048-site tile, with
+    leading sites of a run masked, and a run straddling every kind of boundary."""
+    rng = np.random.default_rng(5)
+    S = 3 * 2048 + 77
+    arr = rng.integers(0, 4, size=(5, S), dtype=np.uint8)
+    arr[rng.random(arr.shape) < 0.6] = 78
+    lens = rng.choice([1, 2, 31, 32, 33, 64, 500, 2047, 2049], size=200)
+    loc = np.repeat(np.arange(200, dtype=np.uint32), lens)[:S]
+    loc = np.concatenate([loc, np.full(S - len(loc), 999, np.uint32)]) if len(loc) < S else loc
+    tmap = np.stack([loc, np.arange(S, dtype=np.uint32)], axis=1)
+    from tetrad_amd import synth
+    quartets = synth.all_quartets(5)
+    engine.set_data(arr, tmap)
+    _, _, _, dbg = engine.resolve(quartets, True, debug=True)
+    _, _, _, o = oracle.new_infer_resolved_quartets(arr, tmap, quartets, True, debug=True)
+    np.testing.assert_array_equal(dbg["cmats"], o["cmats"])
+
+
+def test_error_behaviour(oracle):
+    from tetrad_amd.engine import QuartetEngine, TetradHipError
+    with QuartetEngine(0) as eng:
+        with pytest.raises(TetradHipError) as e:
+            eng.resolve(np.array([[0, 1, 2, 3]], np.uint32), False)
+        assert e.value.code == -4                                   # TQ_ERR_NO_DATA
+        arr = np.zeros((5, 10), np.uint8)
+        tmap = np.zeros((10, 2), np.uint32)
+        tmap[:, 0] = [0, 0, 1, 1, 0, 0, 2, 2, 3, 3]                 # locus 0 re-appears
+        eng.set_data(arr, tmap)
+        with pytest.raises(TetradHipError) as e:
+            eng.resolve(np.array([[0, 1, 2, 9]], np.uint32), False)
+        assert e.value.code == -1                                   # taxon index >= T
+        with pytest.raises(TetradHipError) as e:
+            eng.resolve(np.array([[0, 1, 2, 3]], np.uint32), True)
+        assert e.value.code == -5                                   # TQ_ERR_LOCUS_ORDER
+        rstat, rscor, flags = eng.resolve(np.array([[0, 1, 2, 3]], np.uint32), False)
+        assert flags[0] & 1 and rstat[0, 1] == 0 and np.all(rscor == 0.001)
+        rstat, rscor, flags = eng.resolve(np.zeros((0, 4), np.uint32), False)
+        assert rstat.shape == (0, 2)
+
+
+def test_device_pointer_api_and_unranking(engine):
+    """tq_resolve_dev / tq_resolve_range_dev / tq_unrank_dev agree with the host-buffer API."""
+    import torch
+    from tetrad_amd import synth
+    g = load_golden("c1_T16_S5000")
+    engine.set_data(g["tmparr"], g["tmpmap"])
+    Q = 1820
+    dev = torch.device("cuda:0")
+    dq = torch.zeros((Q, 4), dtype=torch.int32, device=dev)
+    rstat = torch.zeros((Q, 2), dtype=torch.int32, device=dev)
+    rscor = torch.zeros((Q, 3), dtype=torch.float64, device=dev)
+    flags = torch.zeros(Q, dtype=torch.uint8, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+    engine.resolve_range_dev(0, Q, True, dq.data_ptr(), rstat.data_ptr(), rscor.data_ptr(),
+                             flags.data_ptr(), stream)
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(dq.cpu().numpy().astype(np.uint32), g["quartets"])
+    np.testing.assert_array_equal(rstat.cpu().numpy().astype(np.uint32), g["sub_rstat"])
+    h_rstat, h_rscor, h_flags = engine.resolve(g["quartets"], True)
+    np.testing.assert_array_equal(rscor.cpu().numpy(), h_rscor)
+    # random ranks -> quartets
+    ranks = np.random.default_rng(0).choice(1820, size=500, replace=False).astype(np.int64)
+    dr = torch.from_numpy(ranks).to(dev)
+    dq2 = torch.zeros((500, 4), dtype=torch.int32, device=dev)
+    engine.unrank_dev(dr.data_ptr(), 500, dq2.data_ptr(), stream)
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(dq2.cpu().numpy().astype(np.uint32), synth.unrank_quartets(ranks, 16))
+    rstat2 = torch.zeros((500, 2), dtype=torch.int32, device=dev)
+    rscor2 = torch.zeros((500, 3), dtype=torch.float64, device=dev)
+    engine.resolve_dev(dq2.data_ptr(), 500, True, rstat2.data_ptr(), rscor2.data_ptr(), 0, stream)
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(rstat2.cpu().numpy().astype(np.uint32), g["sub_rstat"][ranks])
+
+
+def test_full_size_properties_c3(engine):
+    """At BASELINE.json's c3 size (128 taxa, 50k SNPs): size-independent properties.
+
+    (1) chunk invariance / determinism; (2) nsnps bounds; (3) relabelling symmetry: swapping
+    the last two taxa of a quartet swaps flattenings 1 and 2 (and leaves 0), swapping the
+    middle two swaps flattenings 0 and 1; (4) sum of the count matrix equals nsnps."""
+    from tetrad_amd import synth
+    tmparr, tmpmap = synth.simulate_tmparr(128, 50_000, synth.CONFIG_SEEDS["c3"])
+    engine.set_data(tmparr, tmpmap)
+    q = synth.random_quartets(128, 6000, seed=99)
+    nloci = len(np.unique(tmpmap[:, 0]))
+    for sub in (False, True):
+        rstat, rscor, flags = engine.resolve(q, sub)
+        a = [engine.resolve(q[i:i + 1111], sub) for i in range(0, len(q), 1111)]
+        np.testing.assert_array_equal(rstat, np.concatenate([x[0] for x in a]))
+        np.testing.assert_array_equal(rscor, np.concatenate([x[1] for x in a]))
+        assert (flags == 0).all(), "benchmark data must have no degenerate / zero-data quartets"
+        assert (rstat[:, 1] <= (nloci if sub else 50_000)).all() and (rstat[:, 1] > 0).all()
+        # relabelling symmetry
+        q_cd = q[:, [0, 1, 3, 2]]
+        r2, s2, _ = engine.resolve(q_cd, sub)
+        np.testing.assert_array_equal(r2[:, 1], rstat[:, 1])
+        smax = np.abs(rscor).max(axis=1, keepdims=True) * 1e3
+        assert_close(s2[:, [0, 2, 1]], rscor, smax, "scores under c<->d swap")
+        np.testing.assert_array_equal(r2[:, 0], np.array([0, 2, 1])[rstat[:, 0]])
+        q_bc = q[:, [0, 2, 1, 3]]
+        r3, s3, _ = engine.resolve(q_bc, sub)
+        assert_close(s3[:, [1, 0, 2]], rscor, smax, "scores under b<->c swap")
+        np.testing.assert_array_equal(r3[:, 0], np.array([1, 0, 2])[rstat[:, 0]])
+        _, _, _, dbg = engine.resolve(q[:200], sub, debug=True)
+        np.testing.assert_array_equal(dbg["cmats"].sum(axis=(2, 3)), np.repeat(rstat[:200, 1:2], 3, axis=1))
+    full = engine.resolve(q, False)[0][:, 1]
+    sub_ = engine.resolve(q, True)[0][:, 1]
+    assert (sub_ <= full).all()

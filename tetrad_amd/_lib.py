@@ -1,0 +1,97 @@
+"""ctypes binding of libtetrad_hip.so (the C ABI declared in include/tetrad_hip.h).
+
+There is no CPU fallback: if the HIP library is missing or cannot be loaded the
+import-time helper raises, and every compute entry point raises TetradHipError
+on a non-zero return code (message from tq_last_error).
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import shutil
+import subprocess
+from pathlib import Path
+
+CSRC = Path(__file__).resolve().parent / "csrc"
+LIB_PATH = CSRC / "libtetrad_hip.so"
+SRC_PATH = CSRC / "tetrad_hip.hip"
+HEADER = Path(__file__).resolve().parents[1] / "include" / "tetrad_hip.h"
+
+TQ_OK = 0
+ERR_NAMES = {
+    -1: "TQ_ERR_INVALID_ARG", -2: "TQ_ERR_NO_DEVICE", -3: "TQ_ERR_HIP",
+    -4: "TQ_ERR_NO_DATA", -5: "TQ_ERR_LOCUS_ORDER", -6: "TQ_ERR_OOM",
+}
+FLAG_ZERO_DATA, FLAG_DEGENERATE, FLAG_BAD_INDEX = 1, 2, 4
+
+#: every symbol include/tetrad_hip.h declares (checked by tests/test_cabi_symbols.py)
+SYMBOLS = [
+    "tq_create", "tq_destroy", "tq_last_error", "tq_set_data", "tq_resolve",
+    "tq_resolve_dev", "tq_resolve_range_dev", "tq_unrank_dev", "tq_resolve_debug",
+    "tq_timing_enable", "tq_timing_read", "tq_set_option", "tq_device_info",
+]
+
+
+class TetradHipError(RuntimeError):
+    def __init__(self, code: int, message: str):
+        self.code = code
+        super().__init__(f"{ERR_NAMES.get(code, code)}: {message}")
+
+
+def build(force: bool = False, verbose: bool = False) -> Path:
+    """Compile the HIP library in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    newest_src = max(SRC_PATH.stat().st_mtime, HEADER.stat().st_mtime)
+    if not force and LIB_PATH.exists() and LIB_PATH.stat().st_mtime >= newest_src:
+        return LIB_PATH
+    cmd = [hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared",
+           "-o", str(LIB_PATH), str(SRC_PATH)]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def load() -> ctypes.CDLL:
+    """Load libtetrad_hip.so and declare every prototype.  Raises if it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIB_PATH.exists():
+        raise ImportError(
+            f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc, gfx950).  tetrad_amd has no CPU fallback.")
+    lib = ctypes.CDLL(str(LIB_PATH))
+    c = ctypes
+    vp, i64, i32 = c.c_void_p, c.c_int64, c.c_int
+    lib.tq_create.argtypes = [c.POINTER(vp), i32]
+    lib.tq_create.restype = i32
+    lib.tq_destroy.argtypes = [vp]
+    lib.tq_destroy.restype = None
+    lib.tq_last_error.argtypes = [vp]
+    lib.tq_last_error.restype = c.c_char_p
+    lib.tq_set_data.argtypes = [vp, vp, i64, i64, vp, i64]
+    lib.tq_set_data.restype = i32
+    lib.tq_resolve.argtypes = [vp, vp, i64, i32, vp, vp, vp]
+    lib.tq_resolve.restype = i32
+    lib.tq_resolve_dev.argtypes = [vp, vp, i64, i32, vp, vp, vp, vp]
+    lib.tq_resolve_dev.restype = i32
+    lib.tq_resolve_range_dev.argtypes = [vp, c.c_uint64, i64, i32, vp, vp, vp, vp, vp]
+    lib.tq_resolve_range_dev.restype = i32
+    lib.tq_unrank_dev.argtypes = [vp, vp, i64, vp, vp]
+    lib.tq_unrank_dev.restype = i32
+    lib.tq_resolve_debug.argtypes = [vp, vp, i64, i32, vp, vp, vp, vp, vp, vp]
+    lib.tq_resolve_debug.restype = i32
+    lib.tq_timing_enable.argtypes = [vp, i32]
+    lib.tq_timing_enable.restype = i32
+    lib.tq_timing_read.argtypes = [vp, c.POINTER(c.c_double), c.POINTER(i64)]
+    lib.tq_timing_read.restype = i32
+    lib.tq_set_option.argtypes = [vp, c.c_char_p, i64]
+    lib.tq_set_option.restype = i32
+    lib.tq_device_info.argtypes = [vp, c.POINTER(c.c_int32), c.POINTER(c.c_int32), c.POINTER(i64)]
+    lib.tq_device_info.restype = i32
+    _lib = lib
+    return lib

@@ -1,0 +1,133 @@
+"""QuartetEngine: one HIP context on one GPU (thin object wrapper over the C ABI).
+
+Holds one replicate's genotype matrix resident in HBM (`set_data`, once per
+replicate) and resolves quartet chunks against it.  Mirrors the state an
+ipyparallel engine has in the reference while it runs
+`infer_resolved_quartets` (tetrad/src/resolve_quartets.py:17-39) -- minus the
+per-chunk HDF5 re-read.
+"""
+from __future__ import annotations
+
+import ctypes
+
+import numpy as np
+
+from . import _lib
+from ._lib import TetradHipError
+
+
+def _ptr(a):
+    return ctypes.c_void_p(a.ctypes.data) if a is not None else None
+
+
+class QuartetEngine:
+    def __init__(self, device_id: int = 0):
+        self._lib = _lib.load()
+        h = ctypes.c_void_p()
+        rc = self._lib.tq_create(ctypes.byref(h), int(device_id))
+        if rc != 0:
+            raise TetradHipError(rc, self._lib.tq_last_error(None).decode())
+        self._h = h
+        self.device_id = int(device_id)
+        self.T = self.S = 0
+
+    # -- lifecycle ---------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.tq_destroy(self._h)
+            self._h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc: int):
+        if rc != 0:
+            raise TetradHipError(rc, self._lib.tq_last_error(self._h).decode())
+
+    # -- data --------------------------------------------------------------
+    def set_data(self, tmparr: np.ndarray, tmpmap: np.ndarray):
+        """tmparr u8[T,S]; tmpmap u32[S,2] (column 0 used) or a 1-D locus column."""
+        tmparr = np.ascontiguousarray(tmparr, dtype=np.uint8)
+        if tmparr.ndim != 2:
+            raise ValueError("tmparr must be 2-D [ntaxa, nsites]")
+        tmpmap = np.asarray(tmpmap)
+        if tmpmap.ndim == 2:
+            tm = np.ascontiguousarray(tmpmap, dtype=np.uint32)
+            stride = tm.shape[1]
+        else:
+            tm = np.ascontiguousarray(tmpmap, dtype=np.uint32)
+            stride = 1
+        if tm.shape[0] != tmparr.shape[1]:
+            raise ValueError("tmpmap rows must equal tmparr columns")
+        T, S = tmparr.shape
+        self._check(self._lib.tq_set_data(self._h, _ptr(tmparr), T, S, _ptr(tm), stride))
+        self.T, self.S = T, S
+
+    def set_option(self, name: str, value: int) -> int:
+        rc = self._lib.tq_set_option(self._h, name.encode(), int(value))
+        if rc < 0:
+            self._check(rc)
+        return rc
+
+    # -- host-buffer API -----------------------------------------------------
+    def resolve(self, quartets: np.ndarray, subsample_snps: bool = True, debug: bool = False):
+        """Returns (rstat u32[Q,2], rscor f64[Q,3], flags u8[Q]) and, with ``debug``,
+        a dict with cmats u32[Q,3,16,16], svds f64[Q,3,16], ranks i32[Q,3]."""
+        q = np.ascontiguousarray(quartets, dtype=np.uint32).reshape(-1, 4)
+        Q = q.shape[0]
+        rstat = np.zeros((Q, 2), np.uint32)
+        rscor = np.zeros((Q, 3), np.float64)
+        flags = np.zeros(Q, np.uint8)
+        if debug:
+            cm = np.zeros((Q, 3, 16, 16), np.uint32)
+            sv = np.zeros((Q, 3, 16), np.float64)
+            rk = np.zeros((Q, 3), np.int32)
+            self._check(self._lib.tq_resolve_debug(
+                self._h, _ptr(q), Q, int(bool(subsample_snps)), _ptr(rstat), _ptr(rscor),
+                _ptr(flags), _ptr(cm), _ptr(sv), _ptr(rk)))
+            return rstat, rscor, flags, dict(cmats=cm, svds=sv, ranks=rk)
+        self._check(self._lib.tq_resolve(
+            self._h, _ptr(q), Q, int(bool(subsample_snps)), _ptr(rstat), _ptr(rscor), _ptr(flags)))
+        return rstat, rscor, flags
+
+    # -- device-pointer API (addresses as ints, e.g. torch.Tensor.data_ptr()) -------
+    def resolve_dev(self, d_quartets: int, Q: int, subsample_snps: bool, d_rstat: int,
+                    d_rscor: int, d_flags: int = 0, stream: int = 0):
+        self._check(self._lib.tq_resolve_dev(
+            self._h, d_quartets, Q, int(bool(subsample_snps)), d_rstat, d_rscor,
+            d_flags or None, stream or None))
+
+    def resolve_range_dev(self, first_rank: int, Q: int, subsample_snps: bool, d_quartets: int,
+                          d_rstat: int, d_rscor: int, d_flags: int = 0, stream: int = 0):
+        self._check(self._lib.tq_resolve_range_dev(
+            self._h, first_rank, Q, int(bool(subsample_snps)), d_quartets or None, d_rstat,
+            d_rscor, d_flags or None, stream or None))
+
+    def unrank_dev(self, d_ranks: int, Q: int, d_quartets: int, stream: int = 0):
+        self._check(self._lib.tq_unrank_dev(self._h, d_ranks, Q, d_quartets, stream or None))
+
+    # -- measurement -----------------------------------------------------------
+    def timing_enable(self, on: bool = True):
+        self._check(self._lib.tq_timing_enable(self._h, int(on)))
+
+    def timing_read(self):
+        ms = ctypes.c_double()
+        n = ctypes.c_int64()
+        self._check(self._lib.tq_timing_read(self._h, ctypes.byref(ms), ctypes.byref(n)))
+        return ms.value, n.value
+
+    def device_info(self):
+        cu = ctypes.c_int32()
+        w = ctypes.c_int32()
+        pitch = ctypes.c_int64()
+        self._check(self._lib.tq_device_info(self._h, ctypes.byref(cu), ctypes.byref(w), ctypes.byref(pitch)))
+        return dict(num_cu=cu.value, waves_per_cu=w.value, row_pitch=pitch.value)

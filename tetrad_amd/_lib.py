@@ -64,6 +64,12 @@ def load() -> ctypes.CDLL:
         raise ImportError(
             f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc, gfx950).  tetrad_amd has no CPU fallback.")
+    # One HIP runtime per process: PyTorch-ROCm ships its own libamdhip64.so.7 and must be the
+    # first to load it, otherwise torch.cuda (device buffers, streams, RCCL) finds no GPU.
+    try:
+        import torch  # noqa: F401
+    except ImportError:  # torch is plumbing, not a requirement of the host-buffer API
+        pass
     lib = ctypes.CDLL(str(LIB_PATH))
     c = ctypes
     vp, i64, i32 = c.c_void_p, c.c_int64, c.c_int

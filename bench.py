@@ -86,6 +86,7 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--nrep", type=int, default=0)
     ap.add_argument("--waves-per-cu", type=int, default=0)
+    ap.add_argument("--phases", type=int, default=0, help="diagnostic: 1 scan only, 2 SVD only (invalid as a result)")
     args = ap.parse_args()
 
     import torch
@@ -121,6 +122,8 @@ def main():
         eng.set_option("nrep", args.nrep)
     if args.waves_per_cu:
         eng.set_option("waves_per_cu", args.waves_per_cu)
+    if args.phases:
+        eng.set_option("phases", args.phases)
     eng.set_data(tmparr, tmpmap)
 
     d_q = torch.from_numpy(quartets.astype(np.int32)).to(dev)
@@ -189,7 +192,9 @@ def main():
                          "algorithmic_bytes_per_launch": bytes_per_launch},
             "flags": {"zero_data": int((flags & 1).sum()), "degenerate": int(((flags & 2) > 0).sum())},
         }
-        if not args.no_cpu:
+        if args.phases in (1, 2):
+            line["INVALID_diagnostic_phases"] = args.phases
+        if not args.no_cpu and args.phases in (0, 3):
             cb, parity = cpu_baseline(tmparr, tmpmap, quartets, sub, rstat, rscor)
             line["cpu_baseline"] = cb
             line["parity_on_cpu_sample"] = parity

@@ -390,7 +390,9 @@ __device__ __forceinline__ int flat_bin(int t, int r, int j)
     return hi + 4 * (j & 3) + (r & 3);
 }
 
-template <int NREP, bool SUB, bool DEBUG>
+// PHASES: 3 = product kernel; 1 = scan only, 2 = singular values only (timing diagnostics, outputs
+// are not meaningful: selected with tq_set_option("phases", ...), never by the product path)
+template <int NREP, bool SUB, bool DEBUG, int PHASES = 3>
 __global__ void __launch_bounds__(WAVE)
 tq_resolve_kernel(DevData d, const uint32_t *__restrict__ quartets, int64_t Q, OutPtrs out)
 {
@@ -424,9 +426,16 @@ tq_resolve_kernel(DevData d, const uint32_t *__restrict__ quartets, int64_t Q, O
                 const uint32_t T = (uint32_t)d.T;
                 bad = (q[0] >= T) | (q[1] >= T) | (q[2] >= T) | (q[3] >= T);
                 if (!bad) {
-                    scan_quartet<NREP, SUB>(d, q, hist, lane);
-                    __syncthreads();
-                    nsn = fold_hist<NREP>(hist, cmi, lane);
+                    if (PHASES & 1) {
+                        scan_quartet<NREP, SUB>(d, q, hist, lane);
+                        __syncthreads();
+                        nsn = fold_hist<NREP>(hist, cmi, lane);
+                    } else {
+                        // synthetic full-rank counts so the SVD stage does representative work
+                        for (int k = lane; k < 256; k += WAVE)
+                            cmi[k] = (k % 85 == 0) ? 0u : ((q[0] * 131u + q[1] * 71u + q[2] * 31u + q[3] * 7u + k * 2654435761u) >> 20) % 997u;
+                        nsn = 1;
+                    }
                 }
             }
             if ((qi >= Q) | bad) {
@@ -442,6 +451,14 @@ tq_resolve_kernel(DevData d, const uint32_t *__restrict__ quartets, int64_t Q, O
         // ---------------- phase 2: three flattenings per 16-lane group ----------------
         const int64_t myq = wg * QPW + grp;
         const uint32_t *cmq = cm + 256 * grp;
+        if (!(PHASES & 2)) {
+            if (j == 0 && myq < Q) {
+                out.rstat[myq * 2 + 0] = cmq[1];
+                out.rstat[myq * 2 + 1] = my_nsnps;
+            }
+            __syncthreads();
+            continue;
+        }
         double sig[3];
         int pos[3], rnk[3];
         double smax_all = 0.0;
@@ -523,6 +540,7 @@ struct tq_ctx {
     // options
     int nrep = 8;
     int waves_per_cu = 0;           // 0 = from the occupancy query
+    int phases = 3;                 // diagnostics only: 1 = scan only, 2 = SVD only
     // timing
     bool timing = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
@@ -589,10 +607,10 @@ DevData dev_data(const tq_ctx *ctx)
     return d;
 }
 
-template <int NREP, bool SUB, bool DEBUG>
+template <int NREP, bool SUB, bool DEBUG, int PHASES = 3>
 int launch_t(tq_ctx *ctx, const uint32_t *d_quartets, int64_t Q, const OutPtrs &out, hipStream_t stream)
 {
-    auto kern = tq_resolve_kernel<NREP, SUB, DEBUG>;
+    auto kern = tq_resolve_kernel<NREP, SUB, DEBUG, PHASES>;
     int wpc = ctx->waves_per_cu;
     if (wpc <= 0) {
         int nb = 0;
@@ -630,6 +648,12 @@ int launch_n(tq_ctx *ctx, const uint32_t *dq, int64_t Q, int subsample, bool deb
         return subsample ? launch_t<NREP, true, true>(ctx, dq, Q, out, stream)
                          : launch_t<NREP, false, true>(ctx, dq, Q, out, stream);
     }
+    if (ctx->phases == 1)
+        return subsample ? launch_t<NREP, true, false, 1>(ctx, dq, Q, out, stream)
+                         : launch_t<NREP, false, false, 1>(ctx, dq, Q, out, stream);
+    if (ctx->phases == 2)
+        return subsample ? launch_t<NREP, true, false, 2>(ctx, dq, Q, out, stream)
+                         : launch_t<NREP, false, false, 2>(ctx, dq, Q, out, stream);
     return subsample ? launch_t<NREP, true, false>(ctx, dq, Q, out, stream)
                      : launch_t<NREP, false, false>(ctx, dq, Q, out, stream);
 }
@@ -900,6 +924,12 @@ int tq_set_option(tq_ctx *ctx, const char *name, int64_t value)
         if (value < 0 || value > 32) return fail(ctx, TQ_ERR_INVALID_ARG, "waves_per_cu must be 0..32");
         ctx->waves_per_cu = (int)value;
         return ctx->waves_per_cu;
+    }
+    if (!strcmp(name, "phases")) {
+        if (value != 0 && value != 1 && value != 2 && value != 3)
+            return fail(ctx, TQ_ERR_INVALID_ARG, "phases must be 1, 2 or 3");
+        ctx->phases = value ? (int)value : 3;
+        return ctx->phases;
     }
     return fail(ctx, TQ_ERR_INVALID_ARG, "unknown option '%s'", name);
 }

@@ -12,7 +12,8 @@ from __future__ import annotations
 import numpy as np
 
 EPS = np.finfo(np.float64).eps
-TOL = 2.0 ** -50          # rotate while |g| > TOL * sqrt(a*b)
+TOL = 2.0 ** -50          # rotate while g^2 > TOL^2 * a*b
+EARLY = 1e-5              # a sweep whose largest pre-rotation |g|/sqrt(a*b) is below this is the last
 MAX_SWEEPS = 30
 
 
@@ -29,7 +30,7 @@ def jacobi_singular_values(mats: np.ndarray, tol: float = TOL, max_sweeps: int =
         # columns whose norm fell below eps * (largest column norm) are numerically
         # zero (16x below numpy's rank threshold); they are frozen, not rotated
         zthr = (EPS * EPS) * nrm.max(axis=1, keepdims=True)
-        rotated = np.zeros(N, dtype=bool)
+        again = np.zeros(N, dtype=bool)
         for m in range(1, 16):
             partner = lanes ^ m
             B = A[:, :, partner]                   # partner column (shuffle)
@@ -38,11 +39,12 @@ def jacobi_singular_values(mats: np.ndarray, tol: float = TOL, max_sweeps: int =
             lo = lanes < partner                   # this lane plays 'p' (lower index)
             alpha = np.where(lo, nrm, nb)
             beta = np.where(lo, nb, nrm)
-            do = (np.abs(g) > tol * np.sqrt(alpha * beta)) & (np.minimum(alpha, beta) > zthr) \
-                & active[:, None]
-            gs = np.where(do, g, 1.0)
-            zeta = (beta - alpha) / (2.0 * gs)
-            t = np.where(zeta >= 0, 1.0, -1.0) / (np.abs(zeta) + np.sqrt(1.0 + zeta * zeta))
+            live = np.minimum(alpha, beta) > zthr
+            do = live & (g * g > tol * tol * alpha * beta) & active[:, None]
+            again |= (live & (g * g > EARLY * EARLY * alpha * beta)).any(axis=1)
+            d = beta - alpha
+            h = 2.0 * np.where(do, g, 0.5)
+            t = np.where(d < 0, -1.0, 1.0) * h / (np.abs(d) + np.sqrt(d * d + h * h))
             c = 1.0 / np.sqrt(1.0 + t * t)
             s = c * t
             # lane lo: new = c*own - s*other ; lane hi: new = c*own + s*other
@@ -52,9 +54,8 @@ def jacobi_singular_values(mats: np.ndarray, tol: float = TOL, max_sweeps: int =
             A = c[:, None, :] * A + sg[:, None, :] * B
             tg = np.where(do, t * g, 0.0)
             nrm = np.maximum(np.where(lo, nrm - tg, nrm + tg), 0.0)
-            rotated |= do.any(axis=1)
         sweeps[active] += 1
-        active &= rotated
+        active &= again
         if not active.any():
             break
     sv = np.sqrt(np.einsum("nrc,nrc->nc", A, A))

@@ -51,6 +51,7 @@ constexpr int TILE = WAVE * SITES_PER_LANE;        // 2048 sites per wave step
 constexpr int QPW = 4;                              // quartets per wave pass (one per 16-lane group)
 constexpr double F64_EPS = 2.220446049250313e-16;
 constexpr double JTOL2 = 7.888609052210118e-31;     // (2^-50)^2 : rotate while g^2 > JTOL2*a*b
+constexpr double JEARLY2 = 1e-10;                   // (1e-5)^2 : see jacobi16
 constexpr int MAX_SWEEPS = 30;
 constexpr double DEGENERATE_REL_GAP = 1e-9;
 
@@ -298,6 +299,54 @@ __device__ __forceinline__ uint32_t fold_hist(uint32_t *hist, uint32_t *cm, int 
 // ------------------------------------------------------------------------------------
 __device__ __forceinline__ double shx(double v, int m) { return __shfl_xor(v, m, WAVE); }
 
+// XOR-partner exchange inside a 16-lane row with DPP moves (VALU) instead of ds_bpermute_b32:
+// the LDS crossbar is one unit per CU and a bpermute holds it for 4 cycles, which made the SVD
+// stage LDS-issue bound (profiles/r01_v1_baseline).  gfx9 DPP offers the involutions
+// quad_perm (lane^1, ^2, ^3), row_half_mirror (lane^7), row_ror:8 (lane^8), row_mirror (lane^15);
+// every other XOR mask is a product of two of them.
+template <int CTRL>
+__device__ __forceinline__ int dpp_mov(int v)
+{
+    return __builtin_amdgcn_mov_dpp(v, CTRL, 0xF, 0xF, true);
+}
+
+template <int Q>
+__device__ __forceinline__ int dpp_quad_xor(int v)
+{
+    static_assert(Q >= 1 && Q <= 3, "quad xor");
+    return Q == 1 ? dpp_mov<0xB1>(v) : Q == 2 ? dpp_mov<0x4E>(v) : dpp_mov<0x1B>(v);
+}
+
+template <int M>
+__device__ __forceinline__ int dpp_xor16(int v)
+{
+    static_assert(M >= 1 && M <= 15, "xor mask within a 16-lane row");
+    constexpr int DPP_ROW_MIRROR = 0x140, DPP_ROW_HALF_MIRROR = 0x141, DPP_ROW_ROR8 = 0x128;
+    if constexpr (M == 15) return dpp_mov<DPP_ROW_MIRROR>(v);
+    else if constexpr (M == 7) return dpp_mov<DPP_ROW_HALF_MIRROR>(v);
+    else if constexpr (M == 8) return dpp_mov<DPP_ROW_ROR8>(v);
+    else if constexpr (M >= 12) return dpp_quad_xor<(M & 3) ^ 3>(dpp_mov<DPP_ROW_MIRROR>(v));
+    else if constexpr (M >= 9) return dpp_quad_xor<M & 3>(dpp_mov<DPP_ROW_ROR8>(v));
+    else if constexpr (M >= 4) return dpp_quad_xor<(M & 3) ^ 3>(dpp_mov<DPP_ROW_HALF_MIRROR>(v));
+    else return dpp_quad_xor<M>(v);
+}
+
+template <int M>
+__device__ __forceinline__ double dpx(double v)
+{
+    const int lo = dpp_xor16<M>(__double2loint(v));
+    const int hi = dpp_xor16<M>(__double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
+
+template <int M>
+__device__ __forceinline__ void exchange_col(const double (&a)[16], double nrm, double (&b)[16], double &nb)
+{
+#pragma unroll
+    for (int r = 0; r < 16; ++r) b[r] = dpx<M>(a[r]);
+    nb = dpx<M>(nrm);
+}
+
 __device__ __forceinline__ double group_max(double v)
 {
 #pragma unroll
@@ -319,34 +368,91 @@ struct SvResult {
     double smax;
 };
 
+// f64 reciprocal / reciprocal square root from the hardware estimate (v_rcp_f64 / v_rsq_f64)
+// plus Newton steps.  NR = 1 gives >= ~2^-45 (enough for the rotation tangent, whose error only
+// affects convergence speed), NR = 2 gives full f64 precision (needed for the cosine, which
+// scales the columns and therefore the singular values).  tools/probe_math.hip measures both.
+template <int NR>
+__device__ __forceinline__ double rcp_nr(double v)
+{
+    double r = __builtin_amdgcn_rcp(v);
+#pragma unroll
+    for (int i = 0; i < NR; ++i) r = fma(fma(-v, r, 1.0), r, r);
+    return r;
+}
+
+template <int NR>
+__device__ __forceinline__ double rsq_nr(double v)
+{
+    double y = __builtin_amdgcn_rsq(v);
+#pragma unroll
+    for (int i = 0; i < NR; ++i) y = fma(0.5 * y, fma(-v * y, y, 1.0), y);
+    return y;
+}
+
 // One-sided Jacobi, XOR-partner ordering.  Mirrors tests/jacobi_model.py step for step.
+//   rotation of the pair (p,q), p < q, alpha = |a_p|^2, beta = |a_q|^2, g = a_p.a_q:
+//     d = beta - alpha, h = 2g, t = sign(d) * h / (|d| + sqrt(d^2 + h^2))   (smaller root)
+//     c = 1/sqrt(1 + t^2), s = c*t ;  a_p <- c*a_p - s*a_q ;  a_q <- s*a_p + c*a_q
+//   a pair is rotated while g^2 > JTOL2*alpha*beta; a sweep in which no pair exceeded
+//   JEARLY2 before its rotation is the last one (quadratic convergence squares the
+//   remaining off-diagonal, (1e-5)^2 << 2^-50, so the verification sweep is skipped).
 __device__ __forceinline__ SvResult jacobi16(double (&a)[16], int j, int lane)
 {
+    // a 16-lane group stops rotating when ITS matrix has converged, whatever the other three
+    // groups of the wave still do: results do not depend on which quartets share a wave
+    bool active = true;
     for (int sweep = 0; sweep < MAX_SWEEPS; ++sweep) {
         double nrm = 0.0;
 #pragma unroll
         for (int r = 0; r < 16; ++r) nrm = fma(a[r], a[r], nrm);
         // columns below eps * (largest column norm) are numerically zero: frozen, not rotated
         const double zthr = (F64_EPS * F64_EPS) * group_max(nrm);
-        bool rotated = false;
+        bool again = false;
 #pragma unroll 1
         for (int m = 1; m < 16; ++m) {
             double b[16];
+            double nb;
+            switch (m) {                       // wave-uniform: one scalar branch per round
+            case 1: exchange_col<1>(a, nrm, b, nb); break;
+            case 2: exchange_col<2>(a, nrm, b, nb); break;
+            case 3: exchange_col<3>(a, nrm, b, nb); break;
+            case 4: exchange_col<4>(a, nrm, b, nb); break;
+            case 5: exchange_col<5>(a, nrm, b, nb); break;
+            case 6: exchange_col<6>(a, nrm, b, nb); break;
+            case 7: exchange_col<7>(a, nrm, b, nb); break;
+            case 8: exchange_col<8>(a, nrm, b, nb); break;
+            case 9: exchange_col<9>(a, nrm, b, nb); break;
+            case 10: exchange_col<10>(a, nrm, b, nb); break;
+            case 11: exchange_col<11>(a, nrm, b, nb); break;
+            case 12: exchange_col<12>(a, nrm, b, nb); break;
+            case 13: exchange_col<13>(a, nrm, b, nb); break;
+            case 14: exchange_col<14>(a, nrm, b, nb); break;
+            default: exchange_col<15>(a, nrm, b, nb); break;
+            }
+            double g0 = 0.0, g1 = 0.0;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) b[r] = shx(a[r], m);
-            const double nb = shx(nrm, m);
-            double g = 0.0;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) g = fma(a[r], b[r], g);
+            for (int r = 0; r < 16; r += 2) {
+                g0 = fma(a[r], b[r], g0);
+                g1 = fma(a[r + 1], b[r + 1], g1);
+            }
+            const double g = g0 + g1;
             const bool lo = j < (j ^ m);
             const double alpha = lo ? nrm : nb;
             const double beta = lo ? nb : nrm;
-            const bool doit = (g * g > JTOL2 * alpha * beta) && (fmin(alpha, beta) > zthr);
+            const double ab = alpha * beta;
+            const double gg = g * g;
+            const bool live = fmin(alpha, beta) > zthr;
+            const bool doit = active && live && (gg > JTOL2 * ab);
+            again |= live && (gg > JEARLY2 * ab);
             if (__any(doit)) {
-                const double gs = doit ? g : 1.0;
-                const double zeta = (beta - alpha) / (2.0 * gs);
-                const double t = copysign(1.0, zeta) / (fabs(zeta) + sqrt(fma(zeta, zeta, 1.0)));
-                double c = 1.0 / sqrt(fma(t, t, 1.0));
+                const double d = beta - alpha;
+                const double h = doit ? g + g : 1.0;
+                const double x = fma(d, d, h * h);
+                const double rr = x * rsq_nr<1>(x);                    // sqrt(d^2 + h^2)
+                const double tt = h * rcp_nr<1>(fabs(d) + rr);
+                const double t = (d < 0.0) ? -tt : tt;
+                double c = rsq_nr<2>(fma(t, t, 1.0));
                 double sg = lo ? -(c * t) : (c * t);
                 c = doit ? c : 1.0;
                 sg = doit ? sg : 0.0;
@@ -354,10 +460,10 @@ __device__ __forceinline__ SvResult jacobi16(double (&a)[16], int j, int lane)
                 for (int r = 0; r < 16; ++r) a[r] = fma(sg, b[r], c * a[r]);
                 const double tg = doit ? t * g : 0.0;
                 nrm = fmax(lo ? nrm - tg : nrm + tg, 0.0);
-                rotated |= doit;
             }
         }
-        if (!__any(rotated)) break;
+        active = active && (((__ballot(again) >> (lane & 48)) & 0xFFFFull) != 0);
+        if (!__any(active)) break;
     }
     double nrm = 0.0;
 #pragma unroll

@@ -113,12 +113,15 @@ int tq_resolve_debug(tq_ctx *ctx, const uint32_t *quartets, int64_t Q, int subsa
                      uint32_t *rstat, double *rscor, uint8_t *flags,
                      uint32_t *cmats, double *svds, int32_t *ranks);
 
-/* HIP-event timing of the resolve kernel, on the stream it was launched on.
- * tq_timing_enable(ctx, 1) makes every subsequent resolve launch record a
- * start/stop event pair; tq_timing_read synchronises those events, returns the
- * summed kernel milliseconds and launch count since the last reset, and resets. */
+/* HIP-event timing of the two resolve kernels, on the stream they were launched on.
+ * tq_timing_enable(ctx, 1) makes every subsequent resolve call record HIP events
+ * around its kernels; tq_timing_read synchronises those events, returns the summed
+ * kernel milliseconds and the number of resolve calls since the last reset, and resets. */
 int tq_timing_enable(tq_ctx *ctx, int on);
 int tq_timing_read(tq_ctx *ctx, double *kernel_ms, int64_t *launches);
+/* Same, split by kernel: total = scan + svd milliseconds summed over the `calls` resolve calls
+ * made since the last read (a resolve call launches one scan + one SVD kernel per batch).     */
+int tq_timing_read_split(tq_ctx *ctx, double *total_ms, double *scan_ms, double *svd_ms, int64_t *calls);
 
 /* Tuning knobs (0 = library default).  Returns the value in effect. */
 int tq_set_option(tq_ctx *ctx, const char *name, int64_t value);

@@ -28,7 +28,7 @@ FLAG_ZERO_DATA, FLAG_DEGENERATE, FLAG_BAD_INDEX = 1, 2, 4
 SYMBOLS = [
     "tq_create", "tq_destroy", "tq_last_error", "tq_set_data", "tq_resolve",
     "tq_resolve_dev", "tq_resolve_range_dev", "tq_unrank_dev", "tq_resolve_debug",
-    "tq_timing_enable", "tq_timing_read", "tq_set_option", "tq_device_info",
+    "tq_timing_enable", "tq_timing_read", "tq_timing_read_split", "tq_set_option", "tq_device_info",
 ]
 
 
@@ -95,6 +95,9 @@ def load() -> ctypes.CDLL:
     lib.tq_timing_enable.restype = i32
     lib.tq_timing_read.argtypes = [vp, c.POINTER(c.c_double), c.POINTER(i64)]
     lib.tq_timing_read.restype = i32
+    lib.tq_timing_read_split.argtypes = [vp, c.POINTER(c.c_double), c.POINTER(c.c_double),
+                                         c.POINTER(c.c_double), c.POINTER(i64)]
+    lib.tq_timing_read_split.restype = i32
     lib.tq_set_option.argtypes = [vp, c.c_char_p, i64]
     lib.tq_set_option.restype = i32
     lib.tq_device_info.argtypes = [vp, c.POINTER(c.c_int32), c.POINTER(c.c_int32), c.POINTER(i64)]

@@ -8,29 +8,30 @@
 // quartet during the singular-value stage.
 //
 // Data layout in HBM (built once per replicate by tq_set_data):
-//   rows   u8  [T][Sp]   base code 0..3 per site, missing/pad -> 0   (Sp = S rounded up to 2048)
-//   miss   u32 [T][W]    1 bit per site, 1 = missing or pad           (W  = Sp/32)
-//   p0,p1  u32 [T][W]    bit-planes of the base code (subsample mode only)
-//   runbeg u32 [W]       1 bit per site, 1 = site starts a new locus run
+//   rows   u8   [T][Sp]  base code 0..3 per site, missing/pad -> 0    (Sp = S rounded up to 2048)
+//   planes u32x4[T][W]   per 32 sites: {missing bits, base bit 0, base bit 1, run-begin bits}
+//                        (W = Sp/32; run-begin = site starts a new locus run, same for every row,
+//                        replicated so that one 16-byte load brings everything a lane needs)
 //
-// Kernel tq_resolve_kernel, one wavefront per workgroup, persistent grid:
-//   phase 1 (x4 quartets): wave scans a quartet 2048 sites per step.  Lane l owns 32
-//     consecutive sites: 2 x dwordx4 per row (coalesced 2 KiB per row per step) plus one
-//     bit-plane word per row.  The "count this site" mask C is pure bit logic on 32-site
-//     words (missing, variable-among-4, first-unmasked-site-of-locus via an adder carry
-//     chain, cross-lane carries resolved on the scalar unit from two ballots).  The 8-bit
-//     site pattern (a<<6|b<<4|c<<2|d) is built 4 sites per VALU op (SWAR); uncounted sites
-//     are steered to bin 0 (AAAA) -- invariant patterns can never be counted, so the four
-//     invariant bins double as dump bins and are cleared afterwards.  Counts go to an LDS
-//     histogram with NREP lane-interleaved replicas (ds_add_u32).
-//   phase 2: each 16-lane group takes one quartet; lane j holds column j (16 f64) of a
-//     flattening and the group runs a one-sided (Hestenes) Jacobi SVD with the XOR-partner
-//     parallel ordering (15 rounds per sweep, partner = lane ^ m).  Rank rule, minrank,
-//     tail-norm scores and argmin follow resolve_quartets.py:241-251.
+// Kernel 1, tq_scan_kernel: one wavefront per quartet, persistent grid.  The wave scans 2048
+//   sites per step; lane l owns 32 consecutive sites: 2 x dwordx4 of each of the 4 rows
+//   (coalesced 2 KiB per row per step) + one 16-byte plane record per row, prefetched one step
+//   ahead.  Which sites count is pure bit logic on 32-site words: U = variable-among-the-4 &
+//   ~missing (resolve_quartets.py:216-218); in subsample mode additionally "first unmasked site
+//   of its locus run" (:58-64) via an adder carry chain, cross-lane carries resolved on the
+//   scalar unit from two ballots.  The 8-bit site pattern (a<<6|b<<4|c<<2|d) is built 4 sites
+//   per VALU op (SWAR) and counted with EXEC-masked ds_add_u32 into an LDS histogram with NREP
+//   lane-interleaved replicas; the folded 256 counts go to a scratch slab cm[Q][256] (1 KiB per
+//   quartet, L2/MALL resident between the two kernels).
+// Kernel 2, tq_svd_kernel: each 16-lane group takes one quartet; lane j holds column j (16 f64)
+//   of a flattening and the group runs a one-sided (Hestenes) Jacobi SVD with the XOR-partner
+//   parallel ordering (15 rounds per sweep, partner = lane ^ m, exchanged with DPP moves).  Rank
+//   rule, minrank, tail-norm scores and argmin follow resolve_quartets.py:241-251.
 //
-// Bounds: the scan is L2/LDS/VALU work on a <= 26 MB matrix (HBM only on first touch), the
-// SVD is f64 VALU.  Algorithmic bytes per quartet are 4*S + 48.
+// Bounds: the scan is L2 / LDS-atomic / VALU work on a <= 40 MB resident matrix (HBM only on
+// first touch), the SVD is f64 VALU.  Algorithmic bytes per quartet: 4*S + 48.
 #include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
 
 #include <cstdarg>
 #include <cstdint>
@@ -48,7 +49,7 @@ namespace {
 constexpr int WAVE = 64;
 constexpr int SITES_PER_LANE = 32;
 constexpr int TILE = WAVE * SITES_PER_LANE;        // 2048 sites per wave step
-constexpr int QPW = 4;                              // quartets per wave pass (one per 16-lane group)
+constexpr int QPW = 4;                              // quartets per wave pass of the SVD kernel
 constexpr double F64_EPS = 2.220446049250313e-16;
 constexpr double JTOL2 = 7.888609052210118e-31;     // (2^-50)^2 : rotate while g^2 > JTOL2*a*b
 constexpr double JEARLY2 = 1e-10;                   // (1e-5)^2 : see jacobi16
@@ -57,9 +58,9 @@ constexpr double DEGENERATE_REL_GAP = 1e-9;
 
 struct DevData {
     const uint8_t *rows;
-    const uint32_t *miss, *p0, *p1, *runbeg;
+    const uint4 *planes;
     int64_t pitch;      // bytes per row (Sp)
-    int64_t W;          // bit-plane words per row (Sp/32)
+    int64_t W;          // plane records per row (Sp/32)
     int32_t T;
     int32_t ntiles;     // Sp / TILE
 };
@@ -74,19 +75,18 @@ struct OutPtrs {
 };
 
 // ------------------------------------------------------------------------------------
-// data preparation kernels
+// data preparation kernel: one thread per 32-site word of one taxon row
 // ------------------------------------------------------------------------------------
-// one thread per 32-site word of one taxon row
-__global__ void tq_prepare_rows(const uint8_t *__restrict__ raw, int64_t S, int64_t Sp, int64_t W,
-                                int32_t T, uint8_t *__restrict__ rows, uint32_t *__restrict__ miss,
-                                uint32_t *__restrict__ p0, uint32_t *__restrict__ p1)
+__global__ void tq_prepare_rows(const uint8_t *__restrict__ raw, const uint32_t *__restrict__ locus,
+                                int64_t S, int64_t Sp, int64_t W, int32_t T, uint8_t *__restrict__ rows,
+                                uint4 *__restrict__ planes)
 {
     int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= (int64_t)T * W) return;
     int64_t t = gid / W, w = gid - t * W;
     const uint8_t *src = raw + t * S + w * 32;
     uint8_t *dst = rows + t * Sp + w * 32;
-    uint32_t mm = 0, b0 = 0, b1 = 0;
+    uint32_t mm = 0, b0 = 0, b1 = 0, rb = 0;
     for (int i = 0; i < 32; ++i) {
         int64_t s = w * 32 + i;
         uint8_t v = (s < S) ? src[i] : (uint8_t)0xFF;
@@ -96,27 +96,12 @@ __global__ void tq_prepare_rows(const uint8_t *__restrict__ raw, int64_t S, int6
         mm |= (uint32_t)missing << i;
         b0 |= (uint32_t)(code & 1) << i;
         b1 |= (uint32_t)((code >> 1) & 1) << i;
-    }
-    miss[t * W + w] = mm;
-    p0[t * W + w] = b0;
-    p1[t * W + w] = b1;
-}
-
-// one thread per 32-site word: run-begin bits of the locus column
-__global__ void tq_prepare_runbeg(const uint32_t *__restrict__ locus, int64_t S, int64_t W,
-                                  uint32_t *__restrict__ runbeg)
-{
-    int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (w >= W) return;
-    uint32_t bits = 0;
-    for (int i = 0; i < 32; ++i) {
-        int64_t s = w * 32 + i;
         if (s < S) {
             bool beg = (s == 0) || (locus[s] != locus[s - 1]);
-            bits |= (uint32_t)beg << i;
+            rb |= (uint32_t)beg << i;
         }
     }
-    runbeg[w] = bits;
+    planes[t * W + w] = make_uint4(mm, b0, b1, rb);
 }
 
 // ------------------------------------------------------------------------------------
@@ -152,17 +137,26 @@ __global__ void tq_unrank_kernel(const uint64_t *__restrict__ ranks, uint64_t fi
     reinterpret_cast<uint4 *>(quartets)[i] = v;
 }
 
+// sort key of a quartet: its first two taxa (quartets sharing them share two of their four rows)
+__global__ void tq_key_kernel(const uint32_t *__restrict__ quartets, int64_t Q, uint32_t T,
+                              uint32_t *__restrict__ keys, uint32_t *__restrict__ idx)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= Q) return;
+    const uint4 q = reinterpret_cast<const uint4 *>(quartets)[i];
+    const uint32_t a = q.x < T ? q.x : T - 1, b = q.y < T ? q.y : T - 1;
+    keys[i] = a * T + b;
+    idx[i] = (uint32_t)i;
+}
+
 // ------------------------------------------------------------------------------------
-// phase 1: site scan -> 256-bin pattern histogram in LDS
+// kernel 1: site scan -> 256-bin pattern histogram
 // ------------------------------------------------------------------------------------
 struct TileRegs {
     uint4 a0, a1, b0, b1, c0, c1, d0, d1;   // 32 site bytes of each of the four rows
-    uint32_t M;                              // OR of the four missing words
-    uint32_t V;                              // variable-among-the-four bits (subsample only)
-    uint32_t B;                              // run-begin bits (subsample only)
+    uint4 pa, pb, pc, pd;                    // plane records {miss, p0, p1, runbeg} of the four rows
 };
 
-template <bool SUB>
 __device__ __forceinline__ void load_tile(TileRegs &r, const DevData &d, const uint32_t (&q)[4], int tile,
                                           int lane)
 {
@@ -176,50 +170,31 @@ __device__ __forceinline__ void load_tile(TileRegs &r, const DevData &d, const u
     r.c0 = pc[0]; r.c1 = pc[1];
     r.d0 = pd[0]; r.d1 = pd[1];
     const int64_t woff = (int64_t)tile * WAVE + lane;
-    const int64_t wa = (int64_t)q[0] * d.W + woff, wb = (int64_t)q[1] * d.W + woff;
-    const int64_t wc = (int64_t)q[2] * d.W + woff, wd = (int64_t)q[3] * d.W + woff;
-    r.M = d.miss[wa] | d.miss[wb] | d.miss[wc] | d.miss[wd];
-    if (SUB) {
-        uint32_t a0 = d.p0[wa], a1 = d.p1[wa];
-        r.V = (a0 ^ d.p0[wb]) | (a1 ^ d.p1[wb]) | (a0 ^ d.p0[wc]) | (a1 ^ d.p1[wc]) |
-              (a0 ^ d.p0[wd]) | (a1 ^ d.p1[wd]);
-        r.B = d.runbeg[woff];
-    } else {
-        r.V = 0;
-        r.B = 0;
-    }
-}
-
-// four sites (one dword of each row) -> four histogram increments
-template <int NREP>
-__device__ __forceinline__ void hist_dword(uint32_t a, uint32_t b, uint32_t c, uint32_t d, uint32_t nib,
-                                           uint32_t *hrep)
-{
-    // base codes are 0..3, so the per-byte pattern (a<<6|b<<4|c<<2|d) never crosses a byte
-    uint32_t pat = (((((a << 2) | b) << 2) | c) << 2) | d;
-    // 4 count bits -> 4 byte masks (bit k -> byte k)
-    uint32_t e = __umul24(nib, 0x204081u) & 0x01010101u;
-    uint32_t keep = (e << 8) - e;
-    uint32_t idx = pat & keep;               // uncounted sites -> bin 0 (an invariant bin)
-    __hip_atomic_fetch_add(&hrep[(idx & 0xFFu) * NREP], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    __hip_atomic_fetch_add(&hrep[((idx >> 8) & 0xFFu) * NREP], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    __hip_atomic_fetch_add(&hrep[((idx >> 16) & 0xFFu) * NREP], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    __hip_atomic_fetch_add(&hrep[(idx >> 24) * NREP], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    r.pa = d.planes[(int64_t)q[0] * d.W + woff];
+    r.pb = d.planes[(int64_t)q[1] * d.W + woff];
+    r.pc = d.planes[(int64_t)q[2] * d.W + woff];
+    r.pd = d.planes[(int64_t)q[3] * d.W + woff];
 }
 
 // Sites to count among this lane's 32 (bit i = site i).
-//   full mode      : every non-missing site; invariant sites land in the invariant bins
-//                    (resolve_quartets.py:216-218 masks them; the bins are cleared later).
-//   subsample mode : unmasked sites that are the first unmasked site of their locus run
-//                    (resolve_quartets.py:58-64).  seen(i) = "an unmasked site precedes i in
-//                    the same run" obeys t(i) = U(i) | (P(i) & t(i-1)) with P = ~runbegin,
+//   U = variable among the four taxa and none missing (resolve_quartets.py:216-218).
+//   full mode      : C = U.
+//   subsample mode : C = sites of U that are the first unmasked site of their locus run
+//                    (resolve_quartets.py:58-64: a site is counted iff unmasked and its locus
+//                    differs from the locus of the previous unmasked site).  seen(i) = "an
+//                    unmasked site precedes i in the same run" obeys
+//                    t(i) = U(i) | (P(i) & t(i-1)), P = ~runbegin, seen(i) = P(i) & t(i-1),
 //                    which is the carry recurrence of the addition (U|P) + U.
 template <bool SUB>
 __device__ __forceinline__ uint32_t count_mask(const TileRegs &r, int lane, uint32_t &tile_carry)
 {
-    if (!SUB) return ~r.M;
-    const uint32_t U = r.V & ~r.M;
-    const uint32_t P = ~r.B;
+    const uint32_t M = r.pa.x | r.pb.x | r.pc.x | r.pd.x;
+    const uint32_t V = (r.pa.y ^ r.pb.y) | (r.pa.z ^ r.pb.z) | (r.pa.y ^ r.pc.y) | (r.pa.z ^ r.pc.z) |
+                       (r.pa.y ^ r.pd.y) | (r.pa.z ^ r.pd.z);
+    const uint32_t U = V & ~M;
+    if (!SUB) return U;
+    const uint32_t B = r.pa.w;
+    const uint32_t P = ~B;
     const uint32_t X = U | P;
     const uint32_t sum = X + U;
     const uint32_t cin0 = sum ^ X ^ U;                       // carry into each bit, lane carry-in = 0
@@ -227,75 +202,153 @@ __device__ __forceinline__ uint32_t count_mask(const TileRegs &r, int lane, uint
     const uint32_t gen = ((X & U) | ((X | U) & ~sum)) >> 31; // carry out of bit 31 = t(31)
     // cross-lane: T(l) = gen(l) | (allprop(l) & T(l-1)); same adder trick on 64-bit ballots (SALU)
     const uint64_t Gm = __ballot(gen != 0);
-    const uint64_t Pm = __ballot(r.B == 0);
+    const uint64_t Pm = __ballot(B == 0);
     const uint64_t Xm = Gm | Pm;
     const uint64_t s1 = Xm + Gm;
     const uint64_t s2 = s1 + (uint64_t)tile_carry;
     const uint64_t cinm = s2 ^ Xm ^ Gm;                      // carry into each lane
-    const uint32_t cout = (uint32_t)((s1 < Xm) | (s2 < s1)); // carry out of lane 63
-    tile_carry = cout;
+    tile_carry = (uint32_t)((s1 < Xm) | (s2 < s1));          // carry out of lane 63
     const uint32_t cin = (uint32_t)(cinm >> lane) & 1u;
     // sites before this lane's first run-begin inherit the incoming "seen" state
-    const uint32_t firstseg = r.B ? ((r.B & (0u - r.B)) - 1u) : 0xFFFFFFFFu;
+    const uint32_t firstseg = B ? ((B & (0u - B)) - 1u) : 0xFFFFFFFFu;
     const uint32_t seen = seen_local | (cin ? firstseg : 0u);
     return U & ~seen;
 }
 
-template <int NREP, bool SUB>
+// four sites (one dword of each row): EXEC-masked histogram increments for the counted ones
+template <int NREP>
+__device__ __forceinline__ void hist_dword(uint32_t a, uint32_t b, uint32_t c, uint32_t d, uint32_t C, int site0,
+                                           uint32_t *hrep)
+{
+    // base codes are 0..3, so the per-byte pattern (a<<6|b<<4|c<<2|d) never crosses a byte
+    const uint32_t pat = (((((a << 2) | b) << 2) | c) << 2) | d;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if (C & (1u << (site0 + k)))
+            __hip_atomic_fetch_add(&hrep[((pat >> (8 * k)) & 0xFFu) * NREP], 1u, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+}
+
+// METHOD 0: one EXEC-masked ds_add per site slot (32 per step, whatever the density).
+// METHOD 1: the lane parks its 32 pattern bytes in LDS and walks the set bits of C: the number of
+//           ds_add per step is the largest per-lane count in the wave (~10 of 32 in subsample
+//           mode, where at most one site per locus run is counted).
+constexpr int PAT_STRIDE = 36;   // bytes per lane in the pattern park (9 dwords: conflict-free b32 stores)
+
+template <int NREP, bool SUB, int METHOD>
+__device__ __forceinline__ void process_tile(const TileRegs &t, int lane, uint32_t &tile_carry, uint32_t *hrep,
+                                             uint8_t *park)
+{
+    const uint32_t C = count_mask<SUB>(t, lane, tile_carry);
+    if (METHOD == 0) {
+        hist_dword<NREP>(t.a0.x, t.b0.x, t.c0.x, t.d0.x, C, 0, hrep);
+        hist_dword<NREP>(t.a0.y, t.b0.y, t.c0.y, t.d0.y, C, 4, hrep);
+        hist_dword<NREP>(t.a0.z, t.b0.z, t.c0.z, t.d0.z, C, 8, hrep);
+        hist_dword<NREP>(t.a0.w, t.b0.w, t.c0.w, t.d0.w, C, 12, hrep);
+        hist_dword<NREP>(t.a1.x, t.b1.x, t.c1.x, t.d1.x, C, 16, hrep);
+        hist_dword<NREP>(t.a1.y, t.b1.y, t.c1.y, t.d1.y, C, 20, hrep);
+        hist_dword<NREP>(t.a1.z, t.b1.z, t.c1.z, t.d1.z, C, 24, hrep);
+        hist_dword<NREP>(t.a1.w, t.b1.w, t.c1.w, t.d1.w, C, 28, hrep);
+    } else {
+        uint32_t *pw = reinterpret_cast<uint32_t *>(park);
+#define TQ_PAT(a, b, c, d) ((((((a) << 2) | (b)) << 2) | (c)) << 2 | (d))
+        pw[0] = TQ_PAT(t.a0.x, t.b0.x, t.c0.x, t.d0.x);
+        pw[1] = TQ_PAT(t.a0.y, t.b0.y, t.c0.y, t.d0.y);
+        pw[2] = TQ_PAT(t.a0.z, t.b0.z, t.c0.z, t.d0.z);
+        pw[3] = TQ_PAT(t.a0.w, t.b0.w, t.c0.w, t.d0.w);
+        pw[4] = TQ_PAT(t.a1.x, t.b1.x, t.c1.x, t.d1.x);
+        pw[5] = TQ_PAT(t.a1.y, t.b1.y, t.c1.y, t.d1.y);
+        pw[6] = TQ_PAT(t.a1.z, t.b1.z, t.c1.z, t.d1.z);
+        pw[7] = TQ_PAT(t.a1.w, t.b1.w, t.c1.w, t.d1.w);
+#undef TQ_PAT
+        uint32_t c = C;
+        while (c) {
+            const int i = __builtin_ctz(c);
+            c &= c - 1;
+            const uint32_t bin = park[i];
+            __hip_atomic_fetch_add(&hrep[bin * NREP], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+    }
+}
+
+// Double-buffered scan: the loads of step t+1 are issued before step t is processed; the
+// sched_barriers keep the compiler from sinking them next to their first use.  The prefetch is
+// unconditional (the index is clamped, so the last step re-reads its own tile): a conditional
+// load would make the compiler merge the buffers with copies that wait for the loads at once.
+template <int NREP, bool SUB, int METHOD>
 __device__ __forceinline__ void scan_quartet(const DevData &d, const uint32_t (&q)[4], uint32_t *hist,
-                                             int lane)
+                                             uint8_t *park, int lane)
 {
     uint32_t *hrep = hist + (lane & (NREP - 1));
     uint32_t tile_carry = 0;
-    TileRegs cur, nxt;
-    load_tile<SUB>(cur, d, q, 0, lane);
-    for (int t = 0; t < d.ntiles; ++t) {
-        if (t + 1 < d.ntiles) load_tile<SUB>(nxt, d, q, t + 1, lane);
-        const uint32_t C = count_mask<SUB>(cur, lane, tile_carry);
-        hist_dword<NREP>(cur.a0.x, cur.b0.x, cur.c0.x, cur.d0.x, (C >> 0) & 15u, hrep);
-        hist_dword<NREP>(cur.a0.y, cur.b0.y, cur.c0.y, cur.d0.y, (C >> 4) & 15u, hrep);
-        hist_dword<NREP>(cur.a0.z, cur.b0.z, cur.c0.z, cur.d0.z, (C >> 8) & 15u, hrep);
-        hist_dword<NREP>(cur.a0.w, cur.b0.w, cur.c0.w, cur.d0.w, (C >> 12) & 15u, hrep);
-        hist_dword<NREP>(cur.a1.x, cur.b1.x, cur.c1.x, cur.d1.x, (C >> 16) & 15u, hrep);
-        hist_dword<NREP>(cur.a1.y, cur.b1.y, cur.c1.y, cur.d1.y, (C >> 20) & 15u, hrep);
-        hist_dword<NREP>(cur.a1.z, cur.b1.z, cur.c1.z, cur.d1.z, (C >> 24) & 15u, hrep);
-        hist_dword<NREP>(cur.a1.w, cur.b1.w, cur.c1.w, cur.d1.w, (C >> 28) & 15u, hrep);
-        cur = nxt;
+    const int last = d.ntiles - 1;
+    TileRegs A, B;
+    load_tile(A, d, q, 0, lane);
+    for (int t = 0; t < d.ntiles; t += 2) {
+        load_tile(B, d, q, min(t + 1, last), lane);
+        __builtin_amdgcn_sched_barrier(0);
+        process_tile<NREP, SUB, METHOD>(A, lane, tile_carry, hrep, park);
+        __builtin_amdgcn_sched_barrier(0);
+        if (t + 1 >= d.ntiles) break;
+        load_tile(A, d, q, min(t + 2, last), lane);
+        __builtin_amdgcn_sched_barrier(0);
+        process_tile<NREP, SUB, METHOD>(B, lane, tile_carry, hrep, park);
+        __builtin_amdgcn_sched_barrier(0);
     }
 }
 
-__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v)
+// cm layout: u32 [Q][256], cm[q][64*i0 + 16*i1 + 4*i2 + i3] = number of counted sites with pattern
+// (i0,i1,i2,i3) -- i.e. mats[0] of resolve_quartets.py:55-64 / :89-95 in row-major order.
+template <int NREP, bool SUB, int METHOD>
+__global__ void __launch_bounds__(WAVE)
+tq_scan_kernel(DevData d, const uint32_t *__restrict__ quartets, const uint32_t *__restrict__ order, int64_t Q,
+               uint32_t *__restrict__ cm)
 {
+    __shared__ uint32_t hist[256 * NREP + (METHOD ? WAVE * PAT_STRIDE / 4 : 0)];
+    const int lane = threadIdx.x;
+    uint8_t *park = reinterpret_cast<uint8_t *>(hist + 256 * NREP) + lane * PAT_STRIDE;
+    for (int i = lane; i < 256 * NREP; i += WAVE) hist[i] = 0;
+    __syncthreads();
+    for (int64_t it = blockIdx.x; it < Q; it += gridDim.x) {
+        // waves that run together work on neighbours of the (a,b)-sorted order, so rows a and b
+        // are L2 hits for all of them; results go to the quartet's original slot
+        const int64_t qi = order ? (int64_t)order[it] : it;
+        const uint4 qv = reinterpret_cast<const uint4 *>(quartets)[qi];
+        uint32_t q[4];
+        q[0] = __builtin_amdgcn_readfirstlane(qv.x);
+        q[1] = __builtin_amdgcn_readfirstlane(qv.y);
+        q[2] = __builtin_amdgcn_readfirstlane(qv.z);
+        q[3] = __builtin_amdgcn_readfirstlane(qv.w);
+        const uint32_t T = (uint32_t)d.T;
+        const bool bad = (q[0] >= T) | (q[1] >= T) | (q[2] >= T) | (q[3] >= T);
+        uint32_t *out = cm + qi * 256;
+        if (bad) {                              // flagged by the SVD kernel; never dereferenced
 #pragma unroll
-    for (int m = 1; m < WAVE; m <<= 1) v += __shfl_xor(v, m, WAVE);
-    return v;
-}
-
-// fold the NREP replicas into cm[256], clear the histogram for the next quartet, clear the
-// four invariant/dump bins (AAAA, CCCC, GGGG, TTTT) and return the number of counted sites
-template <int NREP>
-__device__ __forceinline__ uint32_t fold_hist(uint32_t *hist, uint32_t *cm, int lane)
-{
-    uint32_t tot = 0;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int bin = lane + WAVE * k;
-        uint32_t s = 0;
-#pragma unroll
-        for (int r = 0; r < NREP; ++r) {
-            const int rr = (r + lane) & (NREP - 1);
-            s += hist[bin * NREP + rr];
-            hist[bin * NREP + rr] = 0;
+            for (int k = 0; k < 4; ++k) out[lane + WAVE * k] = 0;
+            continue;
         }
-        if (bin % 85 == 0) s = 0;            // 0, 85, 170, 255
-        cm[bin] = s;
-        tot += s;
+        scan_quartet<NREP, SUB, METHOD>(d, q, hist, park, lane);
+        __syncthreads();
+        // fold the replicas, clear them for the next quartet, store the 256 counts (coalesced)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int bin = lane + WAVE * k;
+            uint32_t s = 0;
+#pragma unroll
+            for (int r = 0; r < NREP; ++r) {
+                const int rr = (r + lane) & (NREP - 1);
+                s += hist[bin * NREP + rr];
+                hist[bin * NREP + rr] = 0;
+            }
+            out[bin] = s;
+        }
+        __syncthreads();
     }
-    return wave_sum_u32(tot);
 }
 
 // ------------------------------------------------------------------------------------
-// phase 2: singular values of a 16x16 matrix, one column per lane of a 16-lane group
+// kernel 2: singular values of a 16x16 matrix, one column per lane of a 16-lane group
 // ------------------------------------------------------------------------------------
 __device__ __forceinline__ double shx(double v, int m) { return __shfl_xor(v, m, WAVE); }
 
@@ -496,88 +549,56 @@ __device__ __forceinline__ int flat_bin(int t, int r, int j)
     return hi + 4 * (j & 3) + (r & 3);
 }
 
-// PHASES: 3 = product kernel; 1 = scan only, 2 = singular values only (timing diagnostics, outputs
-// are not meaningful: selected with tq_set_option("phases", ...), never by the product path)
-template <int NREP, bool SUB, bool DEBUG, int PHASES = 3>
+// kernel 2: count matrices -> singular values, rank, scores, topology
+template <bool DEBUG>
 __global__ void __launch_bounds__(WAVE)
-tq_resolve_kernel(DevData d, const uint32_t *__restrict__ quartets, int64_t Q, OutPtrs out)
+tq_svd_kernel(const uint32_t *__restrict__ cm, const uint32_t *__restrict__ quartets, int64_t Q, int32_t T,
+              OutPtrs out)
 {
-    __shared__ uint32_t lds[256 * NREP + QPW * 256];
-    uint32_t *hist = lds;
-    uint32_t *cm = lds + 256 * NREP;
+    __shared__ uint32_t lds[QPW * 256];
     const int lane = threadIdx.x;
-    const int grp = lane >> 4;      // 16-lane group = quartet slot in phase 2
-    const int j = lane & 15;        // column owned in phase 2
+    const int grp = lane >> 4;      // 16-lane group = quartet slot
+    const int j = lane & 15;        // column owned
 
-    for (int i = lane; i < 256 * NREP; i += WAVE) hist[i] = 0;
-    __syncthreads();
-
-    const int64_t ngroups = (Q + QPW - 1) / QPW;
-    for (int64_t wg = blockIdx.x; wg < ngroups; wg += gridDim.x) {
-        uint32_t my_nsnps = 0;
-        uint32_t my_bad = 0;
-        // ---------------- phase 1: four site scans ----------------
-#pragma unroll 1
-        for (int i = 0; i < QPW; ++i) {
-            const int64_t qi = wg * QPW + i;
-            uint32_t nsn = 0, bad = 0;
-            uint32_t *cmi = cm + 256 * i;
-            if (qi < Q) {
-                const uint4 qv = reinterpret_cast<const uint4 *>(quartets)[qi];
-                uint32_t q[4];
-                q[0] = __builtin_amdgcn_readfirstlane(qv.x);
-                q[1] = __builtin_amdgcn_readfirstlane(qv.y);
-                q[2] = __builtin_amdgcn_readfirstlane(qv.z);
-                q[3] = __builtin_amdgcn_readfirstlane(qv.w);
-                const uint32_t T = (uint32_t)d.T;
-                bad = (q[0] >= T) | (q[1] >= T) | (q[2] >= T) | (q[3] >= T);
-                if (!bad) {
-                    if (PHASES & 1) {
-                        scan_quartet<NREP, SUB>(d, q, hist, lane);
-                        __syncthreads();
-                        nsn = fold_hist<NREP>(hist, cmi, lane);
-                    } else {
-                        // synthetic full-rank counts so the SVD stage does representative work
-                        for (int k = lane; k < 256; k += WAVE)
-                            cmi[k] = (k % 85 == 0) ? 0u : ((q[0] * 131u + q[1] * 71u + q[2] * 31u + q[3] * 7u + k * 2654435761u) >> 20) % 997u;
-                        nsn = 1;
-                    }
-                }
-            }
-            if ((qi >= Q) | bad) {
-                for (int k = lane; k < 256; k += WAVE) cmi[k] = 0;
-            }
-            if (grp == i) {
-                my_nsnps = nsn;
-                my_bad = bad;
+    const int64_t npass = (Q + QPW - 1) / QPW;
+    for (int64_t wg = blockIdx.x; wg < npass; wg += gridDim.x) {
+        // stage the four 1 KiB count slabs of this pass through LDS (coalesced 16-byte loads)
+        {
+            const int64_t q0 = wg * QPW;
+            const uint4 *src = reinterpret_cast<const uint4 *>(cm + q0 * 256);
+            uint4 *dst = reinterpret_cast<uint4 *>(lds);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int idx = lane + WAVE * k;               // 256 uint4 = 4 quartets x 64
+                const bool ok = (q0 + (idx >> 6)) < Q;
+                dst[idx] = ok ? src[idx] : make_uint4(0, 0, 0, 0);
             }
         }
         __syncthreads();
 
-        // ---------------- phase 2: three flattenings per 16-lane group ----------------
         const int64_t myq = wg * QPW + grp;
-        const uint32_t *cmq = cm + 256 * grp;
-        if (!(PHASES & 2)) {
-            if (j == 0 && myq < Q) {
-                out.rstat[myq * 2 + 0] = cmq[1];
-                out.rstat[myq * 2 + 1] = my_nsnps;
-            }
-            __syncthreads();
-            continue;
-        }
+        const uint32_t *cmq = lds + 256 * grp;
         double sig[3];
         int pos[3], rnk[3];
         double smax_all = 0.0;
+        uint32_t my_nsnps = 0;
 #pragma unroll
         for (int t = 0; t < 3; ++t) {
             double a[16];
+            uint32_t colsum = 0;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const uint32_t v = cmq[flat_bin(t, r, j)];
                 a[r] = (double)v;
+                colsum += v;
                 if (DEBUG) {
                     if (out.cmats && myq < Q) out.cmats[((myq * 3 + t) * 16 + r) * 16 + j] = v;
                 }
+            }
+            if (t == 0) {                                        // resolve_quartets.py:226 cmats[0].sum()
+#pragma unroll
+                for (int m = 1; m < 16; m <<= 1) colsum += __shfl_xor(colsum, m, WAVE);
+                my_nsnps = colsum;
             }
             const SvResult sv = jacobi16(a, j, lane);
             sig[t] = sv.sigma;
@@ -589,7 +610,7 @@ tq_resolve_kernel(DevData d, const uint32_t *__restrict__ quartets, int64_t Q, O
                 if (out.ranks && myq < Q && j == 0) out.ranks[myq * 3 + t] = sv.rank;
             }
         }
-        __syncthreads();   // all reads of cm done before the next pass overwrites it
+        __syncthreads();   // all reads of the staged slabs done before the next pass overwrites them
 
         // resolve_quartets.py:246-251
         const int minrank = min(10, min(rnk[0], min(rnk[1], rnk[2])));
@@ -613,7 +634,9 @@ tq_resolve_kernel(DevData d, const uint32_t *__restrict__ quartets, int64_t Q, O
                 sc[0] = sc[1] = sc[2] = 0.001;
                 fl = TQ_FLAG_ZERO_DATA;
             }
-            if (my_bad) fl |= TQ_FLAG_BAD_INDEX;
+            const uint4 qv = reinterpret_cast<const uint4 *>(quartets)[myq];
+            const uint32_t Tu = (uint32_t)T;
+            if ((qv.x >= Tu) | (qv.y >= Tu) | (qv.z >= Tu) | (qv.w >= Tu)) fl |= TQ_FLAG_BAD_INDEX;
             out.rstat[myq * 2 + 0] = (uint32_t)topo;
             out.rstat[myq * 2 + 1] = my_nsnps;
             out.rscor[myq * 3 + 0] = sc[0];
@@ -636,21 +659,32 @@ struct tq_ctx {
     // replicate data
     int64_t T = 0, S = 0, Sp = 0, W = 0;
     uint8_t *d_rows = nullptr;
-    uint32_t *d_planes = nullptr;   // miss | p0 | p1, each T*W words
-    uint32_t *d_runbeg = nullptr;
+    uint4 *d_planes = nullptr;      // [T][W] {miss, p0, p1, runbeg}
     bool have_data = false;
     bool locus_runs_ok = false;
     // scratch for the host-buffer API
     void *d_scratch = nullptr;
     size_t scratch_bytes = 0;
+    // count-matrix slab between the two kernels: u32 [batch][256]
+    uint32_t *d_cm = nullptr;
+    int64_t cm_quartets = 0;
+    // (a,b)-sorted processing order of the current batch: keys/idx in, keys/idx out, cub temp
+    uint32_t *d_sort = nullptr;     // 4 arrays of cm_quartets u32
+    void *d_sort_tmp = nullptr;
+    size_t sort_tmp_bytes = 0;
+    int order = 1;                  // 1 = process quartets in (a,b)-sorted order
     // options
-    int nrep = 8;
+    int nrep = 1;
     int waves_per_cu = 0;           // 0 = from the occupancy query
-    int phases = 3;                 // diagnostics only: 1 = scan only, 2 = SVD only
-    // timing
+    int phases = 3;                 // diagnostics only: 1 = scan kernel only, 2 = SVD kernel only
+    int scan_method = -1;           // 0 = EXEC-masked slot per site, 1 = set-bit walk, -1 = 1 if subsample else 0
+    int64_t batch = 1 << 20;        // quartets per scan->svd batch (1 GiB slab)
+    // timing: per resolve call one (start, mid, stop) triple per batch
     bool timing = false;
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
+    struct Ev { hipEvent_t e0, e1, e2; };
+    std::vector<Ev> events;
     size_t events_used = 0;
+    int64_t timed_calls = 0;
 };
 
 namespace {
@@ -680,10 +714,8 @@ void free_data(tq_ctx *ctx)
 {
     if (ctx->d_rows) (void)hipFree(ctx->d_rows);
     if (ctx->d_planes) (void)hipFree(ctx->d_planes);
-    if (ctx->d_runbeg) (void)hipFree(ctx->d_runbeg);
     ctx->d_rows = nullptr;
     ctx->d_planes = nullptr;
-    ctx->d_runbeg = nullptr;
     ctx->have_data = false;
 }
 
@@ -698,14 +730,51 @@ int ensure_scratch(tq_ctx *ctx, size_t bytes)
     return TQ_OK;
 }
 
+int ensure_cm(tq_ctx *ctx, int64_t quartets)
+{
+    if (quartets <= ctx->cm_quartets) return TQ_OK;
+    if (ctx->d_cm) (void)hipFree(ctx->d_cm);
+    if (ctx->d_sort) (void)hipFree(ctx->d_sort);
+    if (ctx->d_sort_tmp) (void)hipFree(ctx->d_sort_tmp);
+    ctx->d_cm = nullptr;
+    ctx->d_sort = nullptr;
+    ctx->d_sort_tmp = nullptr;
+    ctx->cm_quartets = 0;
+    TQ_HIP(ctx, hipMalloc((void **)&ctx->d_cm, (size_t)quartets * 1024));
+    TQ_HIP(ctx, hipMalloc((void **)&ctx->d_sort, (size_t)quartets * 16));
+    size_t tmp = 0;
+    uint32_t *k = ctx->d_sort;
+    TQ_HIP(ctx, hipcub::DeviceRadixSort::SortPairs(nullptr, tmp, k, k, k, k, (int)quartets));
+    TQ_HIP(ctx, hipMalloc(&ctx->d_sort_tmp, tmp ? tmp : 16));
+    ctx->sort_tmp_bytes = tmp;
+    ctx->cm_quartets = quartets;
+    return TQ_OK;
+}
+
+// order[] for one batch: indices sorted by (first taxon, second taxon); nullptr = natural order
+int make_order(tq_ctx *ctx, const uint32_t *dq, int64_t n, hipStream_t stream, const uint32_t **order)
+{
+    *order = nullptr;
+    if (!ctx->order || n < 1024 || ctx->T > 65535) return TQ_OK;
+    uint32_t *keys_in = ctx->d_sort, *idx_in = keys_in + ctx->cm_quartets;
+    uint32_t *keys_out = idx_in + ctx->cm_quartets, *idx_out = keys_out + ctx->cm_quartets;
+    hipLaunchKernelGGL(tq_key_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, dq, n,
+                       (uint32_t)ctx->T, keys_in, idx_in);
+    TQ_HIP(ctx, hipGetLastError());
+    int bits = 1;
+    while (bits < 32 && (1ull << bits) < (uint64_t)ctx->T * (uint64_t)ctx->T) ++bits;
+    size_t tmp = ctx->sort_tmp_bytes;
+    TQ_HIP(ctx, hipcub::DeviceRadixSort::SortPairs(ctx->d_sort_tmp, tmp, keys_in, keys_out, idx_in, idx_out, (int)n,
+                                                   0, bits, stream));
+    *order = idx_out;
+    return TQ_OK;
+}
+
 DevData dev_data(const tq_ctx *ctx)
 {
     DevData d;
     d.rows = ctx->d_rows;
-    d.miss = ctx->d_planes;
-    d.p0 = ctx->d_planes + ctx->T * ctx->W;
-    d.p1 = ctx->d_planes + 2 * ctx->T * ctx->W;
-    d.runbeg = ctx->d_runbeg;
+    d.planes = ctx->d_planes;
     d.pitch = ctx->Sp;
     d.W = ctx->W;
     d.T = (int32_t)ctx->T;
@@ -713,57 +782,83 @@ DevData dev_data(const tq_ctx *ctx)
     return d;
 }
 
-template <int NREP, bool SUB, bool DEBUG, int PHASES = 3>
-int launch_t(tq_ctx *ctx, const uint32_t *d_quartets, int64_t Q, const OutPtrs &out, hipStream_t stream)
+template <typename K>
+int grid_for(tq_ctx *ctx, K kern, int64_t items, int64_t *grid)
 {
-    auto kern = tq_resolve_kernel<NREP, SUB, DEBUG, PHASES>;
     int wpc = ctx->waves_per_cu;
     if (wpc <= 0) {
         int nb = 0;
         TQ_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, WAVE, 0));
         wpc = nb > 0 ? nb : 8;
     }
-    const int64_t ngroups = (Q + QPW - 1) / QPW;
-    int64_t grid = (int64_t)ctx->prop.multiProcessorCount * wpc;
-    if (grid > ngroups) grid = ngroups;
-    if (grid < 1) grid = 1;
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (ctx->timing) {
-        if (ctx->events_used == ctx->events.size()) {
-            hipEvent_t a, b;
-            TQ_HIP(ctx, hipEventCreate(&a));
-            TQ_HIP(ctx, hipEventCreate(&b));
-            ctx->events.emplace_back(a, b);
-        }
-        e0 = ctx->events[ctx->events_used].first;
-        e1 = ctx->events[ctx->events_used].second;
-        ctx->events_used++;
-        TQ_HIP(ctx, hipEventRecord(e0, stream));
-    }
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(WAVE), 0, stream, dev_data(ctx), d_quartets, Q, out);
-    TQ_HIP(ctx, hipGetLastError());
-    if (ctx->timing) TQ_HIP(ctx, hipEventRecord(e1, stream));
+    int64_t g = (int64_t)ctx->prop.multiProcessorCount * wpc;
+    if (g > items) g = items;
+    if (g < 1) g = 1;
+    *grid = g;
     return TQ_OK;
 }
 
-template <int NREP>
-int launch_n(tq_ctx *ctx, const uint32_t *dq, int64_t Q, int subsample, bool debug, const OutPtrs &out,
-             hipStream_t stream)
+template <int NREP, bool SUB, int METHOD>
+int launch_scan(tq_ctx *ctx, const uint32_t *dq, const uint32_t *order, int64_t Q, hipStream_t stream)
 {
-    if (debug) {
-        return subsample ? launch_t<NREP, true, true>(ctx, dq, Q, out, stream)
-                         : launch_t<NREP, false, true>(ctx, dq, Q, out, stream);
-    }
-    if (ctx->phases == 1)
-        return subsample ? launch_t<NREP, true, false, 1>(ctx, dq, Q, out, stream)
-                         : launch_t<NREP, false, false, 1>(ctx, dq, Q, out, stream);
-    if (ctx->phases == 2)
-        return subsample ? launch_t<NREP, true, false, 2>(ctx, dq, Q, out, stream)
-                         : launch_t<NREP, false, false, 2>(ctx, dq, Q, out, stream);
-    return subsample ? launch_t<NREP, true, false>(ctx, dq, Q, out, stream)
-                     : launch_t<NREP, false, false>(ctx, dq, Q, out, stream);
+    auto kern = tq_scan_kernel<NREP, SUB, METHOD>;
+    int64_t grid;
+    int rc = grid_for(ctx, kern, Q, &grid);
+    if (rc) return rc;
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(WAVE), 0, stream, dev_data(ctx), dq, order, Q, ctx->d_cm);
+    TQ_HIP(ctx, hipGetLastError());
+    return TQ_OK;
 }
 
+int launch_scan_n(tq_ctx *ctx, const uint32_t *dq, const uint32_t *order, int64_t Q, int subsample,
+                  hipStream_t stream)
+{
+#define TQ_SCAN_CASE(N)                                                                              \
+    case N:                                                                                          \
+        if (method == 0)                                                                             \
+            return subsample ? launch_scan<N, true, 0>(ctx, dq, order, Q, stream)                    \
+                             : launch_scan<N, false, 0>(ctx, dq, order, Q, stream);                  \
+        return subsample ? launch_scan<N, true, 1>(ctx, dq, order, Q, stream)                        \
+                         : launch_scan<N, false, 1>(ctx, dq, order, Q, stream)
+    const int method = ctx->scan_method < 0 ? (subsample ? 1 : 0) : ctx->scan_method;
+    switch (ctx->nrep) {
+        TQ_SCAN_CASE(2);
+        TQ_SCAN_CASE(4);
+        TQ_SCAN_CASE(8);
+        TQ_SCAN_CASE(16);
+        TQ_SCAN_CASE(32);
+    default:
+        TQ_SCAN_CASE(1);
+    }
+#undef TQ_SCAN_CASE
+}
+
+template <bool DEBUG>
+int launch_svd(tq_ctx *ctx, const uint32_t *dq, int64_t Q, const OutPtrs &out, hipStream_t stream)
+{
+    auto kern = tq_svd_kernel<DEBUG>;
+    int64_t grid;
+    int rc = grid_for(ctx, kern, (Q + QPW - 1) / QPW, &grid);
+    if (rc) return rc;
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(WAVE), 0, stream, (const uint32_t *)ctx->d_cm, dq, Q,
+                       (int32_t)ctx->T, out);
+    TQ_HIP(ctx, hipGetLastError());
+    return TQ_OK;
+}
+
+OutPtrs offset_out(const OutPtrs &o, int64_t q0)
+{
+    OutPtrs r = o;
+    r.rstat = o.rstat + q0 * 2;
+    r.rscor = o.rscor + q0 * 3;
+    r.flags = o.flags ? o.flags + q0 : nullptr;
+    r.cmats = o.cmats ? o.cmats + q0 * 768 : nullptr;
+    r.svds = o.svds ? o.svds + q0 * 48 : nullptr;
+    r.ranks = o.ranks ? o.ranks + q0 * 3 : nullptr;
+    return r;
+}
+
+// scan kernel -> cm slab -> SVD kernel, in batches so that the slab stays <= batch KiB
 int launch(tq_ctx *ctx, const uint32_t *dq, int64_t Q, int subsample, bool debug, const OutPtrs &out,
            hipStream_t stream)
 {
@@ -772,14 +867,41 @@ int launch(tq_ctx *ctx, const uint32_t *dq, int64_t Q, int subsample, bool debug
         return fail(ctx, TQ_ERR_LOCUS_ORDER,
                     "subsample mode needs each locus id in one contiguous run of sites (and no id 0xFFFFFFFF)");
     if (Q == 0) return TQ_OK;
-    switch (ctx->nrep) {
-    case 1: return launch_n<1>(ctx, dq, Q, subsample, debug, out, stream);
-    case 2: return launch_n<2>(ctx, dq, Q, subsample, debug, out, stream);
-    case 4: return launch_n<4>(ctx, dq, Q, subsample, debug, out, stream);
-    case 16: return launch_n<16>(ctx, dq, Q, subsample, debug, out, stream);
-    case 32: return launch_n<32>(ctx, dq, Q, subsample, debug, out, stream);
-    default: return launch_n<8>(ctx, dq, Q, subsample, debug, out, stream);
+    const int64_t batch = Q < ctx->batch ? Q : ctx->batch;
+    int rc = ensure_cm(ctx, batch);
+    if (rc) return rc;
+    if (ctx->timing) ctx->timed_calls++;
+    for (int64_t q0 = 0; q0 < Q; q0 += batch) {
+        const int64_t n = (Q - q0) < batch ? (Q - q0) : batch;
+        tq_ctx::Ev ev{};
+        if (ctx->timing) {
+            if (ctx->events_used == ctx->events.size()) {
+                tq_ctx::Ev e{};
+                TQ_HIP(ctx, hipEventCreate(&e.e0));
+                TQ_HIP(ctx, hipEventCreate(&e.e1));
+                TQ_HIP(ctx, hipEventCreate(&e.e2));
+                ctx->events.push_back(e);
+            }
+            ev = ctx->events[ctx->events_used++];
+            TQ_HIP(ctx, hipEventRecord(ev.e0, stream));
+        }
+        if (ctx->phases & 1) {
+            const uint32_t *order = nullptr;
+            rc = make_order(ctx, dq + q0 * 4, n, stream, &order);
+            if (rc) return rc;
+            rc = launch_scan_n(ctx, dq + q0 * 4, order, n, subsample, stream);
+            if (rc) return rc;
+        }
+        if (ctx->timing) TQ_HIP(ctx, hipEventRecord(ev.e1, stream));
+        if (ctx->phases & 2) {
+            const OutPtrs o = offset_out(out, q0);
+            rc = debug ? launch_svd<true>(ctx, dq + q0 * 4, n, o, stream)
+                       : launch_svd<false>(ctx, dq + q0 * 4, n, o, stream);
+            if (rc) return rc;
+        }
+        if (ctx->timing) TQ_HIP(ctx, hipEventRecord(ev.e2, stream));
     }
+    return TQ_OK;
 }
 
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -818,9 +940,13 @@ void tq_destroy(tq_ctx *ctx)
     (void)hipSetDevice(ctx->device);
     free_data(ctx);
     if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
-    for (auto &p : ctx->events) {
-        (void)hipEventDestroy(p.first);
-        (void)hipEventDestroy(p.second);
+    if (ctx->d_cm) (void)hipFree(ctx->d_cm);
+    if (ctx->d_sort) (void)hipFree(ctx->d_sort);
+    if (ctx->d_sort_tmp) (void)hipFree(ctx->d_sort_tmp);
+    for (auto &e : ctx->events) {
+        (void)hipEventDestroy(e.e0);
+        (void)hipEventDestroy(e.e1);
+        (void)hipEventDestroy(e.e2);
     }
     delete ctx;
 }
@@ -860,8 +986,7 @@ int tq_set_data(tq_ctx *ctx, const uint8_t *tmparr, int64_t T, int64_t S, const 
     uint8_t *d_raw = nullptr;
     uint32_t *d_loc = nullptr;
     TQ_HIP(ctx, hipMalloc((void **)&ctx->d_rows, (size_t)(T * Sp)));
-    TQ_HIP(ctx, hipMalloc((void **)&ctx->d_planes, (size_t)(3 * T * W) * sizeof(uint32_t)));
-    TQ_HIP(ctx, hipMalloc((void **)&ctx->d_runbeg, (size_t)W * sizeof(uint32_t)));
+    TQ_HIP(ctx, hipMalloc((void **)&ctx->d_planes, (size_t)(T * W) * sizeof(uint4)));
     TQ_HIP(ctx, hipMalloc((void **)&d_raw, (size_t)(T * S)));
     hipError_t e = hipMalloc((void **)&d_loc, (size_t)S * sizeof(uint32_t));
     if (e != hipSuccess) {
@@ -872,11 +997,8 @@ int tq_set_data(tq_ctx *ctx, const uint8_t *tmparr, int64_t T, int64_t S, const 
     if (e == hipSuccess) e = hipMemcpy(d_loc, loc.data(), (size_t)S * sizeof(uint32_t), hipMemcpyHostToDevice);
     if (e == hipSuccess) {
         const int64_t n = T * W;
-        hipLaunchKernelGGL(tq_prepare_rows, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, d_raw, S, Sp, W,
-                           (int32_t)T, ctx->d_rows, ctx->d_planes, ctx->d_planes + T * W,
-                           ctx->d_planes + 2 * T * W);
-        hipLaunchKernelGGL(tq_prepare_runbeg, dim3((unsigned)((W + 255) / 256)), dim3(256), 0, 0, d_loc, S, W,
-                           ctx->d_runbeg);
+        hipLaunchKernelGGL(tq_prepare_rows, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, d_raw, d_loc, S, Sp,
+                           W, (int32_t)T, ctx->d_rows, ctx->d_planes);
         e = hipGetLastError();
         if (e == hipSuccess) e = hipDeviceSynchronize();
     }
@@ -1003,17 +1125,27 @@ int tq_timing_enable(tq_ctx *ctx, int on)
 
 int tq_timing_read(tq_ctx *ctx, double *kernel_ms, int64_t *launches)
 {
+    return tq_timing_read_split(ctx, kernel_ms, nullptr, nullptr, launches);
+}
+
+int tq_timing_read_split(tq_ctx *ctx, double *total_ms, double *scan_ms, double *svd_ms, int64_t *calls)
+{
     if (!ctx) return TQ_ERR_INVALID_ARG;
-    double total = 0.0;
+    double t_scan = 0.0, t_svd = 0.0;
     for (size_t i = 0; i < ctx->events_used; ++i) {
-        TQ_HIP(ctx, hipEventSynchronize(ctx->events[i].second));
-        float ms = 0.f;
-        TQ_HIP(ctx, hipEventElapsedTime(&ms, ctx->events[i].first, ctx->events[i].second));
-        total += ms;
+        TQ_HIP(ctx, hipEventSynchronize(ctx->events[i].e2));
+        float a = 0.f, b = 0.f;
+        TQ_HIP(ctx, hipEventElapsedTime(&a, ctx->events[i].e0, ctx->events[i].e1));
+        TQ_HIP(ctx, hipEventElapsedTime(&b, ctx->events[i].e1, ctx->events[i].e2));
+        t_scan += a;
+        t_svd += b;
     }
-    if (kernel_ms) *kernel_ms = total;
-    if (launches) *launches = (int64_t)ctx->events_used;
+    if (total_ms) *total_ms = t_scan + t_svd;
+    if (scan_ms) *scan_ms = t_scan;
+    if (svd_ms) *svd_ms = t_svd;
+    if (calls) *calls = ctx->timed_calls;
     ctx->events_used = 0;
+    ctx->timed_calls = 0;
     return TQ_OK;
 }
 
@@ -1023,13 +1155,29 @@ int tq_set_option(tq_ctx *ctx, const char *name, int64_t value)
     if (!strcmp(name, "nrep")) {
         if (value == 1 || value == 2 || value == 4 || value == 8 || value == 16 || value == 32) ctx->nrep = (int)value;
         else if (value != 0) return fail(ctx, TQ_ERR_INVALID_ARG, "nrep must be 1,2,4,8,16 or 32");
-        else ctx->nrep = 8;
+        else ctx->nrep = 1;
         return ctx->nrep;
     }
     if (!strcmp(name, "waves_per_cu")) {
         if (value < 0 || value > 32) return fail(ctx, TQ_ERR_INVALID_ARG, "waves_per_cu must be 0..32");
         ctx->waves_per_cu = (int)value;
         return ctx->waves_per_cu;
+    }
+    if (!strcmp(name, "order")) {
+        if (value != 0 && value != 1) return fail(ctx, TQ_ERR_INVALID_ARG, "order must be 0 or 1");
+        ctx->order = (int)value;
+        return ctx->order;
+    }
+    if (!strcmp(name, "scan_method")) {
+        if (value != 0 && value != 1 && value != -1)
+            return fail(ctx, TQ_ERR_INVALID_ARG, "scan_method must be -1 (auto), 0 or 1");
+        ctx->scan_method = (int)value;
+        return ctx->scan_method;
+    }
+    if (!strcmp(name, "batch")) {
+        if (value < 0) return fail(ctx, TQ_ERR_INVALID_ARG, "batch must be >= 0");
+        ctx->batch = value ? value : (1 << 20);
+        return (int)(ctx->batch > 0x7FFFFFFF ? 0x7FFFFFFF : ctx->batch);
     }
     if (!strcmp(name, "phases")) {
         if (value != 0 && value != 1 && value != 2 && value != 3)

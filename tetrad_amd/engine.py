@@ -125,6 +125,14 @@ class QuartetEngine:
         self._check(self._lib.tq_timing_read(self._h, ctypes.byref(ms), ctypes.byref(n)))
         return ms.value, n.value
 
+    def timing_read_split(self):
+        """(total_ms, scan_ms, svd_ms, resolve_calls) since the last read."""
+        tot, a, b = ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
+        n = ctypes.c_int64()
+        self._check(self._lib.tq_timing_read_split(
+            self._h, ctypes.byref(tot), ctypes.byref(a), ctypes.byref(b), ctypes.byref(n)))
+        return tot.value, a.value, b.value, n.value
+
     def device_info(self):
         cu = ctypes.c_int32()
         w = ctypes.c_int32()

@@ -2,8 +2,8 @@
 """Interleaved A/B timing of kernel variants in ONE process (HIP-event kernel time).
 
 usage: python tools/sweep.py [--config c3] [--quartets 200000] [--rounds 3]
-Variants are (mode, nrep, waves_per_cu, phases); phases 1/2 are the scan-only / SVD-only
-diagnostic builds.  Prints one line per variant: median and min kernel ms, quartets/s.
+Variants are (mode, nrep, waves_per_cu).  Prints one line per variant: min total / scan-kernel /
+SVD-kernel milliseconds (tq_timing_read_split) and quartets/s.
 """
 import argparse
 import itertools
@@ -23,8 +23,10 @@ def main():
     ap.add_argument("--rounds", type=int, default=3)
     ap.add_argument("--nreps", default="1,2,4,8,16,32")
     ap.add_argument("--wpcs", default="0")
-    ap.add_argument("--phases", default="3,1,2")
     ap.add_argument("--modes", default="sub,full")
+    ap.add_argument("--methods", default="1")
+    ap.add_argument("--orders", default="1")
+    ap.add_argument("--sort", default="none", choices=["none", "ab", "lex"], help="order of the quartet list")
     args = ap.parse_args()
     import torch
     from tetrad_amd import synth
@@ -34,6 +36,10 @@ def main():
     tmparr, tmpmap = synth.simulate_tmparr(T, S, synth.CONFIG_SEEDS[args.config])
     Q = args.quartets
     quartets = synth.random_quartets(T, Q, 4242)
+    if args.sort == "ab":
+        quartets = quartets[np.argsort(quartets[:, 0].astype(np.int64) * T + quartets[:, 1], kind="stable")]
+    elif args.sort == "lex":
+        quartets = quartets[np.lexsort((quartets[:, 3], quartets[:, 2], quartets[:, 1], quartets[:, 0]))]
     dev = torch.device("cuda:0")
     eng = QuartetEngine(0)
     eng.set_data(tmparr, tmpmap)
@@ -43,25 +49,27 @@ def main():
     stream = torch.cuda.current_stream().cuda_stream
     variants = list(itertools.product(
         args.modes.split(","), [int(x) for x in args.nreps.split(",")],
-        [int(x) for x in args.wpcs.split(",")], [int(x) for x in args.phases.split(",")]))
+        [int(x) for x in args.wpcs.split(",")], [int(x) for x in args.methods.split(",")],
+        [int(x) for x in args.orders.split(",")]))
     times = {v: [] for v in variants}
     eng.timing_enable(True)
     for rnd in range(args.rounds + 1):
         for v in variants:
-            mode, nrep, wpc, ph = v
+            mode, nrep, wpc, meth, order = v
+            eng.set_option("order", order)
+            eng.set_option("scan_method", meth)
             eng.set_option("nrep", nrep)
             eng.set_option("waves_per_cu", wpc)
-            eng.set_option("phases", ph)
             eng.resolve_dev(d_q.data_ptr(), Q, mode == "sub", d_rstat.data_ptr(), d_rscor.data_ptr(), 0, stream)
             torch.cuda.synchronize()
-            ms, n = eng.timing_read()
+            tot, scan, svd, n = eng.timing_read_split()
             if rnd:                     # round 0 is warm-up
-                times[v].append(ms)
-    print(f"# {args.config} T={T} S={S} Q={Q} rounds={args.rounds}")
-    print("mode nrep wpc phases  med_ms   min_ms   Mq/s(min)")
+                times[v].append((tot, scan, svd))
+    print(f"# {args.config} T={T} S={S} Q={Q} rounds={args.rounds} sort={args.sort}")
+    print("mode nrep wpc meth ord total_ms  scan_ms   svd_ms   Mq/s")
     for v in variants:
-        t = np.array(times[v])
-        print(f"{v[0]:4s} {v[1]:4d} {v[2]:3d} {v[3]:6d} {np.median(t):8.3f} {t.min():8.3f} {Q / t.min() / 1e3:9.2f}")
+        t = np.array(times[v]).min(axis=0)
+        print(f"{v[0]:4s} {v[1]:4d} {v[2]:3d} {v[3]:4d} {v[4]:3d} {t[0]:9.3f} {t[1]:8.3f} {t[2]:8.3f} {Q / t[0] / 1e3:7.2f}")
 
 
 if __name__ == "__main__":

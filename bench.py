@@ -12,6 +12,11 @@ rank resolves its own contiguous 1e6-quartet shard of an N x 1e6 global sample.
 Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (HIP-event
 kernel time on the launch stream vs algorithmic bytes, SURVEY.md 8d: A = 4*S + 48 B/quartet)
 and `cpu_baseline` (the oracle -- a port of the reference worker -- timed on host cores).
+
+The hot path is two kernels per batch (tq_scan_kernel: site scan -> 256 pattern counts per
+quartet; tq_svd_kernel: 3 x 16x16 Jacobi SVD -> scores).  `roofline.achieved` prices the
+algorithmic bytes against the SUM of both kernels' HIP-event durations (one pass of the path);
+the per-kernel durations are listed beside it.
 """
 from __future__ import annotations
 
@@ -85,6 +90,7 @@ def main():
     ap.add_argument("--full", action="store_true", help="subsample_snps=False")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--nrep", type=int, default=0)
+    ap.add_argument("--order", type=int, default=-1, help="0 = natural quartet order, 1 = (a,b)-sorted (default)")
     ap.add_argument("--waves-per-cu", type=int, default=0)
     ap.add_argument("--phases", type=int, default=0, help="diagnostic: 1 scan only, 2 SVD only (invalid as a result)")
     args = ap.parse_args()
@@ -124,6 +130,8 @@ def main():
         eng.set_option("waves_per_cu", args.waves_per_cu)
     if args.phases:
         eng.set_option("phases", args.phases)
+    if args.order >= 0:
+        eng.set_option("order", args.order)
     eng.set_data(tmparr, tmpmap)
 
     d_q = torch.from_numpy(quartets.astype(np.int32)).to(dev)
@@ -156,7 +164,7 @@ def main():
         step()
     fence()
     elapsed = time.perf_counter() - t0
-    kernel_ms, launches = eng.timing_read()
+    kernel_ms, scan_ms, svd_ms, launches = eng.timing_read_split()
     eng.timing_enable(False)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -188,7 +196,11 @@ def main():
                        "subsample_snps": sub, "parallelism": f"quartet-sharded x{world} + all-gather"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "tq_resolve_kernel", "kernel_ms": kernel_ms / max(1, launches),
+                         "kernel": "tq_scan_kernel + tq_svd_kernel (one pass of the hot path)",
+                         "kernel_ms": kernel_ms / max(1, launches),
+                         "scan_kernel_ms": scan_ms / max(1, launches),
+                         "svd_kernel_ms": svd_ms / max(1, launches),
+                         "achieved_scan_kernel_only": bytes_per_launch / (scan_ms / max(1, launches) / 1e3) / 1e9,
                          "algorithmic_bytes_per_launch": bytes_per_launch},
             "flags": {"zero_data": int((flags & 1).sum()), "degenerate": int(((flags & 2) > 0).sum())},
         }

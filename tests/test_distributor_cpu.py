@@ -1,0 +1,115 @@
+"""Host logic of the multi-GPU path on CPU: sharding, record packing, world_size-2 gloo gather,
+TSV text.  The per-rank compute step is the oracle here (test infrastructure); on a GPU box the
+default compute is the HIP engine (tests/test_gpu_parity.py covers that path)."""
+import os
+import socket
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from conftest import load_golden
+from tetrad_amd import distributor as D
+
+REPO = Path(__file__).resolve().parents[1]
+
+
+def test_shard_bounds_cover_and_balance():
+    for Q in (0, 1, 7, 8, 1820, 1_000_003):
+        for w in (1, 2, 3, 8):
+            b = D.shard_bounds(Q, w)
+            assert b[0][0] == 0 and b[-1][1] == Q
+            assert all(b[i][1] == b[i + 1][0] for i in range(w - 1))
+            sizes = [hi - lo for lo, hi in b]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_get_chunksize_matches_reference_rule():
+    # run_inference.py:73-96: chunk = nq // (breaks*ncores) + nq % (breaks*ncores)
+    assert D.get_chunksize(1820, 4) == 1820 // 4 + 1820 % 4
+    assert D.get_chunksize(635_376, 8) == 635_376 // (16 * 8) + 635_376 % (16 * 8)
+    assert D.get_chunksize(6_000_000, 8) == 6_000_000 // (32 * 8) + 6_000_000 % (32 * 8)
+    assert D.get_chunksize(3, 80) == 3
+
+
+def test_record_roundtrip_is_bit_exact():
+    rng = np.random.default_rng(0)
+    n = 1000
+    rstat = np.stack([rng.integers(0, 3, n), rng.integers(0, 2**32, n)], axis=1).astype(np.uint32)
+    rscor = rng.standard_normal((n, 3)) * 10.0 ** rng.integers(-300, 300, (n, 3))
+    rscor[0] = [0.001, np.inf, -0.0]
+    rscor[1, 0] = np.nan
+    flags = rng.integers(0, 8, n).astype(np.uint8)
+    a, b, c = D.unpack_records(D.pack_records(rstat, rscor, flags))
+    np.testing.assert_array_equal(a, rstat)
+    np.testing.assert_array_equal(b.view(np.int64), rscor.view(np.int64))
+    np.testing.assert_array_equal(c, flags)
+
+
+def test_tsv_text_equals_reference_pandas_call():
+    """run_inference.py:233-234 builds the rows with pandas; the text must be identical."""
+    import pandas as pd
+    g = load_golden("c1_T16_S5000")
+    rq, rstat, rscor = g["quartets"][:200], g["sub_rstat"][:200], g["sub_rscor"][:200]
+    tabular = pd.concat([pd.DataFrame(i) for i in (rq, rscor, rstat)], axis=1)
+    ref = tabular.to_csv(sep="\t", float_format='%.6f', index=False, header=False)
+    assert D.format_tsv(rq, rscor, rstat) == ref
+
+
+WORKER = r'''
+import os, sys
+import numpy as np
+sys.path.insert(0, sys.argv[1])
+import torch.distributed as dist
+from oracle import oracle as orc
+from tetrad_amd import distributor as D
+rank, world, port, out = int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], sys.argv[5]
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=port, RANK=str(rank), WORLD_SIZE=str(world))
+dist.init_process_group("gloo", rank=rank, world_size=world)
+g = np.load(os.path.join(sys.argv[1], "tests", "golden", "tree_T12_S2000.npz"))
+def compute(tmparr, tmpmap, q, sub):
+    _, rstat, rscor, dbg = orc.new_infer_resolved_quartets(tmparr, tmpmap, q, sub, debug=True)
+    return rstat, rscor, dbg["flags"]
+qr = g["quartets"][:101]                       # odd count: exercises the padded slab
+_, rstat, rscor, flags = D.resolve_sharded(g["tmparr"], g["tmpmap"], qr, True, compute=compute)
+np.savez(out + f".{rank}.npz", rstat=rstat, rscor=rscor, flags=flags)
+# file-writing mirror of run_inference.distributor: only rank 0 writes
+db = out + ".db.npz"
+if rank == 0:
+    np.savez(db, tmparr=g["tmparr"], tmpmap=g["tmpmap"])
+dist.barrier()
+chunks = [qr[i:i + 40].tolist() for i in range(0, 101, 40)]
+D.distributor(db, out + ".tsv", 12, iter(chunks), True, None, compute=compute)
+dist.barrier()
+dist.destroy_process_group()
+'''
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return str(s.getsockname()[1])
+
+
+def test_two_rank_gloo_gather_equals_single_rank(tmp_path, oracle):
+    import subprocess
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    port, out = _free_port(), str(tmp_path / "res")
+    procs = [subprocess.Popen([sys.executable, str(script), str(REPO), str(r), "2", port, out])
+             for r in range(2)]
+    for p in procs:
+        assert p.wait(timeout=300) == 0
+    g = load_golden("tree_T12_S2000")
+    _, rstat, rscor = oracle.new_infer_resolved_quartets(g["tmparr"], g["tmpmap"], g["quartets"][:101], True)
+    for r in range(2):
+        z = np.load(out + f".{r}.npz")
+        np.testing.assert_array_equal(z["rstat"], rstat)              # N-rank == 1-rank, bitwise
+        np.testing.assert_array_equal(z["rscor"], rscor)
+    # rank 0 wrote all chunks in order, 9 columns
+    rows = Path(out + ".tsv").read_text().splitlines()
+    assert len(rows) == 101
+    first = rows[0].split("\t")
+    assert len(first) == 9 and [int(x) for x in first[:4]] == g["quartets"][0].tolist()
+    assert rows[-1].split("\t")[7] == str(int(rstat[100, 0]))

@@ -171,6 +171,12 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # PCIe-inclusive rate of the host-buffer API (quartets H2D + results D2H per call); reported
+    # beside `value`, never as `value`
+    t1 = time.perf_counter()
+    eng.resolve(quartets, sub)
+    pcie_inclusive = Q / (time.perf_counter() - t1)
+
     rstat = d_rstat.cpu().numpy().astype(np.uint32)
     rscor = d_rscor.cpu().numpy()
     flags = d_flags.cpu().numpy()
@@ -202,6 +208,7 @@ def main():
                          "svd_kernel_ms": svd_ms / max(1, launches),
                          "achieved_scan_kernel_only": bytes_per_launch / (scan_ms / max(1, launches) / 1e3) / 1e9,
                          "algorithmic_bytes_per_launch": bytes_per_launch},
+            "pcie_inclusive_value_per_gpu": pcie_inclusive,
             "flags": {"zero_data": int((flags & 1).sum()), "degenerate": int(((flags & 2) > 0).sum())},
         }
         if args.phases in (1, 2):

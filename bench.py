@@ -89,6 +89,8 @@ def main():
     ap.add_argument("--quartets", type=int, default=0, help="quartets per GPU (0 = config default)")
     ap.add_argument("--full", action="store_true", help="subsample_snps=False")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="gloo = rehearsal of the N>1 control flow on a box with fewer GPUs than ranks")
     ap.add_argument("--nrep", type=int, default=0)
     ap.add_argument("--order", type=int, default=-1, help="0 = natural quartet order, 1 = (a,b)-sorted (default)")
     ap.add_argument("--waves-per-cu", type=int, default=0)
@@ -104,12 +106,17 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    ndev = torch.cuda.device_count()
+    dev_index = local_rank if args.backend == "nccl" else local_rank % max(1, ndev)
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
 
     T, S, qdef = synth.CONFIGS[args.config]
     sub = not args.full
@@ -123,7 +130,7 @@ def main():
             synth.comb(T, 4), size=world * Q, replace=False)
         quartets = synth.unrank_quartets(idx[rank * Q:(rank + 1) * Q], T)
 
-    eng = QuartetEngine(local_rank)
+    eng = QuartetEngine(dev_index)
     if args.nrep:
         eng.set_option("nrep", args.nrep)
     if args.waves_per_cu:
@@ -138,17 +145,19 @@ def main():
     d_rstat = torch.zeros((Q, 2), dtype=torch.int32, device=dev)
     d_rscor = torch.zeros((Q, 3), dtype=torch.float64, device=dev)
     d_flags = torch.zeros(Q, dtype=torch.uint8, device=dev)
+    gdev = dev if args.backend == "nccl" else torch.device("cpu")
     if world > 1:
-        g_rstat = torch.zeros((world * Q, 2), dtype=torch.int32, device=dev)
-        g_rscor = torch.zeros((world * Q, 3), dtype=torch.float64, device=dev)
+        g_rstat = torch.zeros((world * Q, 2), dtype=torch.int32, device=gdev)
+        g_rscor = torch.zeros((world * Q, 3), dtype=torch.float64, device=gdev)
     stream = torch.cuda.current_stream().cuda_stream
 
     def step():
         eng.resolve_dev(d_q.data_ptr(), Q, sub, d_rstat.data_ptr(), d_rscor.data_ptr(),
                         d_flags.data_ptr(), stream)
         if world > 1:
-            dist.all_gather_into_tensor(g_rstat, d_rstat)
-            dist.all_gather_into_tensor(g_rscor, d_rscor)
+            # result gather: every rank ends up with the whole node's rows in global order
+            dist.all_gather_into_tensor(g_rstat, d_rstat.to(gdev))
+            dist.all_gather_into_tensor(g_rscor, d_rscor.to(gdev))
 
     def fence():
         if world > 1:
@@ -167,7 +176,7 @@ def main():
     kernel_ms, scan_ms, svd_ms, launches = eng.timing_read_split()
     eng.timing_enable(False)
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=gdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 

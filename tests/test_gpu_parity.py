@@ -17,10 +17,13 @@ RTOL = 1e-6
 ATOL_REL_SMAX = 1e-12
 
 
-@pytest.fixture(scope="module")
-def engine():
+@pytest.fixture(scope="module", params=["hqr", "jacobi"])
+def engine(request):
+    """Every parity test runs against both device SVD paths: Householder + bidiagonal QR
+    (default) and one-sided Jacobi."""
     from tetrad_amd.engine import QuartetEngine
     eng = QuartetEngine(0)
+    eng.set_option("svd_method", 1 if request.param == "hqr" else 0)
     yield eng
     eng.close()
 

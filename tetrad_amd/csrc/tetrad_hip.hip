@@ -347,6 +347,167 @@ tq_scan_kernel(DevData d, const uint32_t *__restrict__ quartets, const uint32_t 
     }
 }
 
+
+// ------------------------------------------------------------------------------------
+// kernel 1, workgroup-cooperative form: NW wavefronts = NW neighbours of the (a,b)-sorted order.
+// Quartets that share their first two taxa share two of their four rows, so the workgroup fetches
+// the rows (and plane records) of taxa a and b ONCE per 2048-site step into LDS (all NW*64 threads
+// cooperate: 384 x 16 B), double-buffered with one barrier per step; every wave still streams its
+// own rows c and d straight to registers.  Cache traffic per quartet falls from 12 KiB to
+// 6 + 6/NW KiB per step -- the scan kernel is L2 / Infinity-Cache bandwidth bound.  A wave whose
+// (a,b) differs from the leader's (group boundary in the sorted order) reads its own a and b
+// from global memory instead; it still takes part in the loads and barriers.
+// ------------------------------------------------------------------------------------
+struct OwnRegs {
+    uint4 c0, c1, d0, d1, pc, pd;
+};
+
+__device__ __forceinline__ void load_own(OwnRegs &r, const DevData &d, uint32_t qc, uint32_t qd, int tile, int lane)
+{
+    const int64_t boff = (int64_t)tile * TILE + lane * SITES_PER_LANE;
+    const uint4 *pc = reinterpret_cast<const uint4 *>(d.rows + (int64_t)qc * d.pitch + boff);
+    const uint4 *pd = reinterpret_cast<const uint4 *>(d.rows + (int64_t)qd * d.pitch + boff);
+    r.c0 = pc[0]; r.c1 = pc[1];
+    r.d0 = pd[0]; r.d1 = pd[1];
+    const int64_t woff = (int64_t)tile * WAVE + lane;
+    r.pc = d.planes[(int64_t)qc * d.W + woff];
+    r.pd = d.planes[(int64_t)qd * d.W + woff];
+}
+
+constexpr int SHARED_PIECES = 384;   // uint4 per step: row a 128, row b 128, planes a 64, planes b 64
+
+__device__ __forceinline__ uint4 load_shared_piece(const DevData &d, uint32_t la, uint32_t lb, int tile, int p)
+{
+    const uint4 *src;
+    if (p < 128) src = reinterpret_cast<const uint4 *>(d.rows + (int64_t)la * d.pitch + (int64_t)tile * TILE) + p;
+    else if (p < 256) src = reinterpret_cast<const uint4 *>(d.rows + (int64_t)lb * d.pitch + (int64_t)tile * TILE) + (p - 128);
+    else if (p < 320) src = d.planes + (int64_t)la * d.W + (int64_t)tile * WAVE + (p - 256);
+    else src = d.planes + (int64_t)lb * d.W + (int64_t)tile * WAVE + (p - 320);
+    return *src;
+}
+
+template <bool SUB, int METHOD, int NW>
+__global__ void __launch_bounds__(NW *WAVE)
+tq_scan_wg_kernel(DevData d, const uint32_t *__restrict__ quartets, const uint32_t *__restrict__ order, int64_t Q,
+                  uint32_t *__restrict__ cm)
+{
+    static_assert(NW * WAVE >= SHARED_PIECES, "one cooperative piece per thread");
+    __shared__ uint4 shared_ab[2][SHARED_PIECES];
+    __shared__ uint32_t hist_all[NW][256];
+    __shared__ uint32_t park_all[NW][WAVE * PAT_STRIDE / 4];
+    const int tid = threadIdx.x;
+    const int w = tid >> 6;
+    const int lane = tid & 63;
+    uint32_t *hist = hist_all[w];
+    uint8_t *park = reinterpret_cast<uint8_t *>(park_all[w]) + lane * PAT_STRIDE;
+    for (int i = lane; i < 256; i += WAVE) hist[i] = 0;
+    const uint32_t T = (uint32_t)d.T;
+    const int last = d.ntiles - 1;
+    const int64_t nblk = (Q + NW - 1) / NW;
+    __syncthreads();
+
+    for (int64_t blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
+        // leader = first quartet of the block; its (a,b) is what the workgroup shares
+        const int64_t it0 = blk * NW;
+        const int64_t lqi = order ? (int64_t)order[it0] : it0;
+        const uint4 lq = reinterpret_cast<const uint4 *>(quartets)[lqi];
+        uint32_t la = __builtin_amdgcn_readfirstlane(lq.x), lb = __builtin_amdgcn_readfirstlane(lq.y);
+        const bool leader_ok = (la < T) & (lb < T);
+        if (!leader_ok) la = lb = 0;
+        // this wave's quartet
+        const int64_t it = it0 + w;
+        const bool have = it < Q;
+        const int64_t qi = have ? (order ? (int64_t)order[it] : it) : 0;
+        const uint4 qv = reinterpret_cast<const uint4 *>(quartets)[qi];
+        uint32_t q[4];
+        q[0] = __builtin_amdgcn_readfirstlane(qv.x);
+        q[1] = __builtin_amdgcn_readfirstlane(qv.y);
+        q[2] = __builtin_amdgcn_readfirstlane(qv.z);
+        q[3] = __builtin_amdgcn_readfirstlane(qv.w);
+        const bool bad = (q[0] >= T) | (q[1] >= T) | (q[2] >= T) | (q[3] >= T);
+        const bool work = have && !bad;                     // wave-uniform
+        const bool shares = work && leader_ok && q[0] == la && q[1] == lb;
+        const uint32_t qc = work ? q[2] : 0, qd = work ? q[3] : 0;
+
+        // prologue: step 0 into buffer 0
+        // LDS slot of piece p: the two 16-byte halves of a lane's 32 row bytes go to separate
+        // 1 KiB panels so that lanes read consecutive 16-byte slots (conflict-free ds_read_b128)
+        const int slot = tid < 256 ? ((tid & 128) | ((tid & 1) << 6) | ((tid & 127) >> 1)) : tid;
+        if (tid < SHARED_PIECES) shared_ab[0][slot] = load_shared_piece(d, la, lb, 0, tid);
+        OwnRegs A, B;
+        load_own(A, d, qc, qd, 0, lane);
+        uint32_t tile_carry = 0;
+        __syncthreads();
+
+        auto step = [&](const OwnRegs &own, int t) {
+            TileRegs r;
+            if (shares) {
+                const uint4 *buf = shared_ab[t & 1];
+                r.a0 = buf[lane];
+                r.a1 = buf[64 + lane];
+                r.b0 = buf[128 + lane];
+                r.b1 = buf[192 + lane];
+                r.pa = buf[256 + lane];
+                r.pb = buf[320 + lane];
+            } else if (work) {                               // group boundary: private rows a and b
+                const int64_t boff = (int64_t)t * TILE + lane * SITES_PER_LANE;
+                const uint4 *pa = reinterpret_cast<const uint4 *>(d.rows + (int64_t)q[0] * d.pitch + boff);
+                const uint4 *pb = reinterpret_cast<const uint4 *>(d.rows + (int64_t)q[1] * d.pitch + boff);
+                r.a0 = pa[0]; r.a1 = pa[1];
+                r.b0 = pb[0]; r.b1 = pb[1];
+                const int64_t woff = (int64_t)t * WAVE + lane;
+                r.pa = d.planes[(int64_t)q[0] * d.W + woff];
+                r.pb = d.planes[(int64_t)q[1] * d.W + woff];
+            }
+            if (work) {
+                r.c0 = own.c0; r.c1 = own.c1;
+                r.d0 = own.d0; r.d1 = own.d1;
+                r.pc = own.pc; r.pd = own.pd;
+                process_tile<1, SUB, METHOD>(r, lane, tile_carry, hist, park);
+            }
+        };
+
+        for (int t = 0; t < d.ntiles; t += 2) {
+            // ---- even step: prefetch t+1 (own -> B, shared -> registers), process A ----
+            {
+                const int tn = min(t + 1, last);
+                uint4 sh = make_uint4(0, 0, 0, 0);
+                if (tid < SHARED_PIECES) sh = load_shared_piece(d, la, lb, tn, tid);
+                load_own(B, d, qc, qd, tn, lane);
+                __builtin_amdgcn_sched_barrier(0);
+                step(A, t);
+                __builtin_amdgcn_sched_barrier(0);
+                if (tid < SHARED_PIECES) shared_ab[(t + 1) & 1][slot] = sh;
+                __syncthreads();
+            }
+            if (t + 1 >= d.ntiles) break;
+            // ---- odd step ----
+            {
+                const int tn = min(t + 2, last);
+                uint4 sh = make_uint4(0, 0, 0, 0);
+                if (tid < SHARED_PIECES) sh = load_shared_piece(d, la, lb, tn, tid);
+                load_own(A, d, qc, qd, tn, lane);
+                __builtin_amdgcn_sched_barrier(0);
+                step(B, t + 1);
+                __builtin_amdgcn_sched_barrier(0);
+                if (tid < SHARED_PIECES) shared_ab[t & 1][slot] = sh;
+                __syncthreads();
+            }
+        }
+        // store the 256 counts of this wave's quartet and clear its histogram
+        if (have) {
+            uint32_t *out = cm + qi * 256;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int bin = lane + WAVE * k;
+                out[bin] = work ? hist[bin] : 0u;
+                hist[bin] = 0;
+            }
+        }
+        __syncthreads();
+    }
+}
+
 // ------------------------------------------------------------------------------------
 // kernel 2: singular values of a 16x16 matrix, one column per lane of a 16-lane group
 // ------------------------------------------------------------------------------------
@@ -895,27 +1056,33 @@ tq_bdsqr_kernel(const double *__restrict__ de, int64_t nmat, double *__restrict_
                 g = hypot_nr(f, 1.0);
                 f = ((x - z) * (x + z) + h * (y * rcp_nr<2>(f + copysign(g, f)) - h)) * rcp_nr<2>(x);
                 double cc = 1.0, ss = 1.0;
+                // one QR sweep over the block [l,k]; the LDS reads of the next step are issued
+                // before the current step's arithmetic, and each hypot shares one rsq with the
+                // reciprocal its rotation needs
+                double gn = E_(l + 1), yn = W_(l + 1);
                 for (int jj = l; jj <= nm; ++jj) {
-                    const int i = jj + 1;
-                    g = E_(i);
-                    y = W_(i);
+                    g = gn;
+                    y = yn;
+                    const int i2 = min(jj + 2, 15);
+                    gn = E_(i2);
+                    yn = W_(i2);
                     h = ss * g;
                     g = cc * g;
-                    z = hypot_nr(f, h);
-                    E_(jj) = z;
-                    double zi = rcp_nr<2>(z);
-                    cc = f * zi;
-                    ss = h * zi;
+                    double zz = fma(f, f, h * h);
+                    double rz = zz > 0.0 ? rsq_nr<2>(zz) : 0.0;
+                    E_(jj) = zz * rz;
+                    cc = f * rz;
+                    ss = h * rz;
                     f = fma(x, cc, g * ss);
                     g = fma(g, cc, -(x * ss));
                     h = y * ss;
                     y *= cc;
-                    z = hypot_nr(f, h);
-                    W_(jj) = z;
-                    if (z != 0.0) {
-                        zi = rcp_nr<2>(z);
-                        cc = f * zi;
-                        ss = h * zi;
+                    zz = fma(f, f, h * h);
+                    rz = zz > 0.0 ? rsq_nr<2>(zz) : 0.0;
+                    W_(jj) = zz * rz;
+                    if (zz > 0.0) {
+                        cc = f * rz;
+                        ss = h * rz;
                     }
                     f = fma(cc, g, ss * y);
                     x = fma(cc, y, -(ss * g));
@@ -1046,6 +1213,7 @@ struct tq_ctx {
     double *d_de = nullptr, *d_sv = nullptr;
     uint32_t *d_nsnps = nullptr;
     int svd_method = 1;             // 0 = one-sided Jacobi (tq_svd_kernel), 1 = Householder + bidiagonal QR
+    int scan_wg = 8;                // waves per workgroup of the cooperative scan kernel (0 = one wave per quartet)
     // options
     int nrep = 1;
     int waves_per_cu = 0;           // 0 = from the occupancy query
@@ -1191,9 +1359,37 @@ int launch_scan(tq_ctx *ctx, const uint32_t *dq, const uint32_t *order, int64_t 
     return TQ_OK;
 }
 
+template <bool SUB, int METHOD, int NW>
+int launch_scan_wg(tq_ctx *ctx, const uint32_t *dq, const uint32_t *order, int64_t Q, hipStream_t stream)
+{
+    auto kern = tq_scan_wg_kernel<SUB, METHOD, NW>;
+    int wgs = ctx->waves_per_cu > 0 ? (ctx->waves_per_cu + NW - 1) / NW : 0;
+    if (wgs <= 0) {
+        int nb = 0;
+        TQ_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, NW * WAVE, 0));
+        wgs = nb > 0 ? nb : 1;
+    }
+    int64_t grid = (int64_t)ctx->prop.multiProcessorCount * wgs;
+    const int64_t nblk = (Q + NW - 1) / NW;
+    if (grid > nblk) grid = nblk;
+    if (grid < 1) grid = 1;
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NW * WAVE), 0, stream, dev_data(ctx), dq, order, Q,
+                       ctx->d_cm);
+    TQ_HIP(ctx, hipGetLastError());
+    return TQ_OK;
+}
+
 int launch_scan_n(tq_ctx *ctx, const uint32_t *dq, const uint32_t *order, int64_t Q, int subsample,
                   hipStream_t stream)
 {
+    if (ctx->scan_wg == 8 && Q >= 64) {
+        const int m = ctx->scan_method < 0 ? (subsample ? 1 : 0) : ctx->scan_method;
+        if (subsample)
+            return m ? launch_scan_wg<true, 1, 8>(ctx, dq, order, Q, stream)
+                     : launch_scan_wg<true, 0, 8>(ctx, dq, order, Q, stream);
+        return m ? launch_scan_wg<false, 1, 8>(ctx, dq, order, Q, stream)
+                 : launch_scan_wg<false, 0, 8>(ctx, dq, order, Q, stream);
+    }
 #define TQ_SCAN_CASE(N)                                                                              \
     case N:                                                                                          \
         if (method == 0)                                                                             \
@@ -1572,6 +1768,11 @@ int tq_set_option(tq_ctx *ctx, const char *name, int64_t value)
         if (value < 0 || value > 32) return fail(ctx, TQ_ERR_INVALID_ARG, "waves_per_cu must be 0..32");
         ctx->waves_per_cu = (int)value;
         return ctx->waves_per_cu;
+    }
+    if (!strcmp(name, "scan_wg")) {
+        if (value != 0 && value != 8) return fail(ctx, TQ_ERR_INVALID_ARG, "scan_wg must be 0 or 8");
+        ctx->scan_wg = (int)value;
+        return ctx->scan_wg;
     }
     if (!strcmp(name, "svd_method")) {
         if (value != 0 && value != 1) return fail(ctx, TQ_ERR_INVALID_ARG, "svd_method must be 0 (Jacobi) or 1 (HQR)");

@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--methods", default="1")
     ap.add_argument("--orders", default="1")
     ap.add_argument("--svds", default="1", help="svd_method list: 0 Jacobi, 1 HQR")
+    ap.add_argument("--wgs", default="8", help="scan_wg list: 0 one wave per quartet, 8 cooperative")
     ap.add_argument("--sort", default="none", choices=["none", "ab", "lex"], help="order of the quartet list")
     args = ap.parse_args()
     import torch
@@ -51,12 +52,14 @@ def main():
     variants = list(itertools.product(
         args.modes.split(","), [int(x) for x in args.nreps.split(",")],
         [int(x) for x in args.wpcs.split(",")], [int(x) for x in args.methods.split(",")],
-        [int(x) for x in args.orders.split(",")], [int(x) for x in args.svds.split(",")]))
+        [int(x) for x in args.orders.split(",")], [int(x) for x in args.svds.split(",")],
+        [int(x) for x in args.wgs.split(",")]))
     times = {v: [] for v in variants}
     eng.timing_enable(True)
     for rnd in range(args.rounds + 1):
         for v in variants:
-            mode, nrep, wpc, meth, order, svdm = v
+            mode, nrep, wpc, meth, order, svdm, wgm = v
+            eng.set_option("scan_wg", wgm)
             eng.set_option("svd_method", svdm)
             eng.set_option("order", order)
             eng.set_option("scan_method", meth)
@@ -68,10 +71,10 @@ def main():
             if rnd:                     # round 0 is warm-up
                 times[v].append((tot, scan, svd))
     print(f"# {args.config} T={T} S={S} Q={Q} rounds={args.rounds} sort={args.sort}")
-    print("mode nrep wpc meth ord svd total_ms  scan_ms   svd_ms   Mq/s")
+    print("mode nrep wpc meth ord svd  wg total_ms  scan_ms   svd_ms   Mq/s")
     for v in variants:
         t = np.array(times[v]).min(axis=0)
-        print(f"{v[0]:4s} {v[1]:4d} {v[2]:3d} {v[3]:4d} {v[4]:3d} {v[5]:3d} {t[0]:9.3f} {t[1]:8.3f} {t[2]:8.3f} {Q / t[0] / 1e3:7.2f}")
+        print(f"{v[0]:4s} {v[1]:4d} {v[2]:3d} {v[3]:4d} {v[4]:3d} {v[5]:3d} {v[6]:3d} {t[0]:9.3f} {t[1]:8.3f} {t[2]:8.3f} {Q / t[0] / 1e3:7.2f}")
 
 
 if __name__ == "__main__":

@@ -13,10 +13,12 @@ Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` 
 kernel time on the launch stream vs algorithmic bytes, SURVEY.md 8d: A = 4*S + 48 B/quartet)
 and `cpu_baseline` (the oracle -- a port of the reference worker -- timed on host cores).
 
-The hot path is two kernels per batch (tq_scan_kernel: site scan -> 256 pattern counts per
-quartet; tq_svd_kernel: 3 x 16x16 Jacobi SVD -> scores).  `roofline.achieved` prices the
-algorithmic bytes against the SUM of both kernels' HIP-event durations (one pass of the path);
-the per-kernel durations are listed beside it.
+The hot path is a short kernel chain per batch: ordering (radix sort by the first two taxa) +
+tq_scan_wg_kernel (site scan -> 256 pattern counts per quartet), then the singular-value stage
+tq_bidiag_kernel + tq_bdsqr_kernel + tq_score_kernel (or tq_svd_kernel, the Jacobi path).
+`roofline.achieved` prices the algorithmic bytes against the SUM of all of them (HIP events on
+the launch stream bracket the scan stage and the singular-value stage of every pass); the two
+stage durations are listed beside it.
 """
 from __future__ import annotations
 
@@ -211,11 +213,11 @@ def main():
                        "subsample_snps": sub, "parallelism": f"quartet-sharded x{world} + all-gather"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "tq_scan_kernel + tq_svd_kernel (one pass of the hot path)",
+                         "kernel": "one pass of the hot path: tq_scan_wg_kernel (+ordering) then tq_bidiag/tq_bdsqr/tq_score",
                          "kernel_ms": kernel_ms / max(1, launches),
-                         "scan_kernel_ms": scan_ms / max(1, launches),
-                         "svd_kernel_ms": svd_ms / max(1, launches),
-                         "achieved_scan_kernel_only": bytes_per_launch / (scan_ms / max(1, launches) / 1e3) / 1e9,
+                         "scan_stage_ms": scan_ms / max(1, launches),
+                         "svd_stage_ms": svd_ms / max(1, launches),
+                         "achieved_scan_stage_only": bytes_per_launch / (scan_ms / max(1, launches) / 1e3) / 1e9,
                          "algorithmic_bytes_per_launch": bytes_per_launch},
             "pcie_inclusive_value_per_gpu": pcie_inclusive,
             "flags": {"zero_data": int((flags & 1).sum()), "degenerate": int(((flags & 2) > 0).sum())},

@@ -241,7 +241,16 @@ __device__ __forceinline__ void process_tile(const TileRegs &t, int lane, uint32
                                              uint8_t *park)
 {
     const uint32_t C = count_mask<SUB>(t, lane, tile_carry);
-    if (METHOD == 0) {
+    if (METHOD == 2) {          // timing diagnostic: everything but the histogram (results are wrong)
+#define TQ_PAT(a, b, c, d) ((((((a) << 2) | (b)) << 2) | (c)) << 2 | (d))
+        uint32_t acc = C;
+        acc ^= TQ_PAT(t.a0.x, t.b0.x, t.c0.x, t.d0.x) ^ TQ_PAT(t.a0.y, t.b0.y, t.c0.y, t.d0.y);
+        acc ^= TQ_PAT(t.a0.z, t.b0.z, t.c0.z, t.d0.z) ^ TQ_PAT(t.a0.w, t.b0.w, t.c0.w, t.d0.w);
+        acc ^= TQ_PAT(t.a1.x, t.b1.x, t.c1.x, t.d1.x) ^ TQ_PAT(t.a1.y, t.b1.y, t.c1.y, t.d1.y);
+        acc ^= TQ_PAT(t.a1.z, t.b1.z, t.c1.z, t.d1.z) ^ TQ_PAT(t.a1.w, t.b1.w, t.c1.w, t.d1.w);
+#undef TQ_PAT
+        asm volatile("" ::"v"(acc));
+    } else if (METHOD == 0) {
         hist_dword<NREP>(t.a0.x, t.b0.x, t.c0.x, t.d0.x, C, 0, hrep);
         hist_dword<NREP>(t.a0.y, t.b0.y, t.c0.y, t.d0.y, C, 4, hrep);
         hist_dword<NREP>(t.a0.z, t.b0.z, t.c0.z, t.d0.z, C, 8, hrep);
@@ -1007,91 +1016,107 @@ tq_bdsqr_kernel(const double *__restrict__ de, int64_t nmat, double *__restrict_
         const int64_t m = wg * WAVE + lane;
         const bool live = m < nmat;
         double anorm = 0.0;
+        double dv[16], ev[16];
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-            const double d = live ? de[m * 32 + i] : 0.0;
-            const double e = live ? de[m * 32 + 16 + i] : 0.0;
-            W_(i) = d;
-            E_(i) = e;
-            anorm = fmax(anorm, fabs(d) + fabs(e));
+            dv[i] = live ? de[m * 32 + i] : 0.0;
+            ev[i] = live ? de[m * 32 + 16 + i] : 0.0;
+            W_(i) = dv[i];
+            E_(i) = ev[i];
+            anorm = fmax(anorm, fabs(dv[i]) + fabs(ev[i]));
         }
         // negligible(x): |x| + anorm == anorm, i.e. |x| <= ~eps/2 * anorm
         const double tiny = anorm * (0.5 * F64_EPS);
-        for (int k = 15; k >= 0; --k) {
-            for (int its = 0; its < 60; ++its) {
-                // find the split point l
-                int l = k;
-                bool cancel = true;
-                for (;;) {
-                    if (l == 0 || fabs(E_(l)) <= tiny) { cancel = false; break; }
-                    if (fabs(W_(l - 1)) <= tiny) break;
-                    --l;
+        // bit i of negE / negW: e[i] / w[i] is negligible.  Kept in registers and updated on every
+        // store, so the split search is a few bit operations instead of a dependent chain of LDS reads.
+        uint32_t negE = 0, negW = 0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            negE |= (uint32_t)(fabs(ev[i]) <= tiny) << i;
+            negW |= (uint32_t)(fabs(dv[i]) <= tiny) << i;
+        }
+#define SET_E(i, v) do { const double v_ = (v); E_(i) = v_; negE = (negE & ~(1u << (i))) | ((uint32_t)(fabs(v_) <= tiny) << (i)); } while (0)
+#define SET_W(i, v) do { const double v_ = (v); W_(i) = v_; negW = (negW & ~(1u << (i))) | ((uint32_t)(fabs(v_) <= tiny) << (i)); } while (0)
+        // Every lane walks its own deflation index k: a lane whose current singular value has
+        // converged moves on at once instead of waiting for the slowest lane of the wave at that k.
+        int k = 15, its = 0;
+        while (k >= 0) {
+            // split point l = largest l <= k with e[l] negligible (or l == 0), unless a negligible
+            // w[l-1] is met first (then e[l] has to be chased out of the block: "cancel")
+            const uint32_t stopE = negE | 1u, stopW = negW << 1;
+            const uint32_t stops = (stopE | stopW) & ((2u << k) - 1u);
+            const int l = 31 - __builtin_clz(stops);
+            const bool cancel = ((stopE >> l) & 1u) == 0;
+            if (cancel) {
+                double cc = 0.0, ss = 1.0;
+                for (int i = l; i <= k; ++i) {
+                    const double ei = E_(i);
+                    const double f = ss * ei;
+                    SET_E(i, cc * ei);
+                    if (fabs(f) <= tiny) break;
+                    const double g = W_(i);
+                    const double h = hypot_nr(f, g);
+                    SET_W(i, h);
+                    const double hi = rcp_nr<2>(h);
+                    cc = g * hi;
+                    ss = -f * hi;
                 }
-                if (cancel) {                       // w[l-1] negligible: chase e[l] out of the block
-                    double cc = 0.0, ss = 1.0;
-                    for (int i = l; i <= k; ++i) {
-                        const double f = ss * E_(i);
-                        E_(i) = cc * E_(i);
-                        if (fabs(f) <= tiny) break;
-                        const double g = W_(i);
-                        const double h = hypot_nr(f, g);
-                        W_(i) = h;
-                        const double hi = rcp_nr<2>(h);
-                        cc = g * hi;
-                        ss = -f * hi;
-                    }
-                }
-                double z = W_(k);
-                if (l == k) {                       // converged
-                    W_(k) = fabs(z);
-                    break;
-                }
-                // shift from the bottom 2x2 minor
-                double x = W_(l);
-                const int nm = k - 1;
-                double y = W_(nm);
-                double g = E_(nm);
-                double h = E_(k);
-                double f = ((y - z) * (y + z) + (g - h) * (g + h)) * rcp_nr<2>(2.0 * h * y);
-                g = hypot_nr(f, 1.0);
-                f = ((x - z) * (x + z) + h * (y * rcp_nr<2>(f + copysign(g, f)) - h)) * rcp_nr<2>(x);
-                double cc = 1.0, ss = 1.0;
-                // one QR sweep over the block [l,k]; the LDS reads of the next step are issued
-                // before the current step's arithmetic, and each hypot shares one rsq with the
-                // reciprocal its rotation needs
-                double gn = E_(l + 1), yn = W_(l + 1);
-                for (int jj = l; jj <= nm; ++jj) {
-                    g = gn;
-                    y = yn;
-                    const int i2 = min(jj + 2, 15);
-                    gn = E_(i2);
-                    yn = W_(i2);
-                    h = ss * g;
-                    g = cc * g;
-                    double zz = fma(f, f, h * h);
-                    double rz = zz > 0.0 ? rsq_nr<2>(zz) : 0.0;
-                    E_(jj) = zz * rz;
+            }
+            double z = W_(k);
+            if (l == k || its >= 60) {          // converged (or iteration cap: keep what we have)
+                W_(k) = fabs(z);
+                --k;
+                its = 0;
+                continue;
+            }
+            ++its;
+            // shift from the bottom 2x2 minor
+            double x = W_(l);
+            const int nm = k - 1;
+            double y = W_(nm);
+            double g = E_(nm);
+            double h = E_(k);
+            double f = ((y - z) * (y + z) + (g - h) * (g + h)) * rcp_nr<2>(2.0 * h * y);
+            g = hypot_nr(f, 1.0);
+            f = ((x - z) * (x + z) + h * (y * rcp_nr<2>(f + copysign(g, f)) - h)) * rcp_nr<2>(x);
+            double cc = 1.0, ss = 1.0;
+            // one QR sweep over the block [l,k]; the LDS reads of the next step are issued
+            // before the current step's arithmetic, and each hypot shares one rsq with the
+            // reciprocal its rotation needs
+            double gn = E_(l + 1), yn = W_(l + 1);
+            for (int jj = l; jj <= nm; ++jj) {
+                g = gn;
+                y = yn;
+                const int i2 = min(jj + 2, 15);
+                gn = E_(i2);
+                yn = W_(i2);
+                h = ss * g;
+                g = cc * g;
+                double zz = fma(f, f, h * h);
+                double rz = zz > 0.0 ? rsq_nr<2>(zz) : 0.0;
+                SET_E(jj, zz * rz);
+                cc = f * rz;
+                ss = h * rz;
+                f = fma(x, cc, g * ss);
+                g = fma(g, cc, -(x * ss));
+                h = y * ss;
+                y *= cc;
+                zz = fma(f, f, h * h);
+                rz = zz > 0.0 ? rsq_nr<2>(zz) : 0.0;
+                SET_W(jj, zz * rz);
+                if (zz > 0.0) {
                     cc = f * rz;
                     ss = h * rz;
-                    f = fma(x, cc, g * ss);
-                    g = fma(g, cc, -(x * ss));
-                    h = y * ss;
-                    y *= cc;
-                    zz = fma(f, f, h * h);
-                    rz = zz > 0.0 ? rsq_nr<2>(zz) : 0.0;
-                    W_(jj) = zz * rz;
-                    if (zz > 0.0) {
-                        cc = f * rz;
-                        ss = h * rz;
-                    }
-                    f = fma(cc, g, ss * y);
-                    x = fma(cc, y, -(ss * g));
                 }
-                E_(l) = 0.0;
-                E_(k) = f;
-                W_(k) = x;
+                f = fma(cc, g, ss * y);
+                x = fma(cc, y, -(ss * g));
             }
+            SET_E(l, 0.0);
+            SET_E(k, f);
+            SET_W(k, x);
         }
+#undef SET_E
+#undef SET_W
         if (live) {
 #pragma unroll
             for (int i = 0; i < 16; ++i) sv[m * 16 + i] = fabs(W_(i));
@@ -1384,6 +1409,7 @@ int launch_scan_n(tq_ctx *ctx, const uint32_t *dq, const uint32_t *order, int64_
 {
     if (ctx->scan_wg == 8 && Q >= 64) {
         const int m = ctx->scan_method < 0 ? (subsample ? 1 : 0) : ctx->scan_method;
+        if (m == 2) return launch_scan_wg<true, 2, 8>(ctx, dq, order, Q, stream);   // diagnostic
         if (subsample)
             return m ? launch_scan_wg<true, 1, 8>(ctx, dq, order, Q, stream)
                      : launch_scan_wg<true, 0, 8>(ctx, dq, order, Q, stream);
@@ -1785,8 +1811,8 @@ int tq_set_option(tq_ctx *ctx, const char *name, int64_t value)
         return ctx->order;
     }
     if (!strcmp(name, "scan_method")) {
-        if (value != 0 && value != 1 && value != -1)
-            return fail(ctx, TQ_ERR_INVALID_ARG, "scan_method must be -1 (auto), 0 or 1");
+        if (value != 0 && value != 1 && value != -1 && value != 2)
+            return fail(ctx, TQ_ERR_INVALID_ARG, "scan_method must be -1 (auto), 0, 1 (or 2: timing diagnostic)");
         ctx->scan_method = (int)value;
         return ctx->scan_method;
     }

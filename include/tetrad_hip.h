@@ -74,6 +74,29 @@ const char *tq_last_error(const tq_ctx *ctx);
 int tq_set_data(tq_ctx *ctx, const uint8_t *tmparr, int64_t T, int64_t S,
                 const uint32_t *locus, int64_t locus_stride);
 
+/* Bootstrap replicates built on the device.
+ * tq_set_source uploads, once per project, what the reference keeps in its HDF5 database for
+ * resampling: `seqarr` (u8 [T,S0], ASCII bases incl. IUPAC two-base codes, N/'-' = missing;
+ * write_database.py:157-159) and `spans` (i64 [nloci,2], [start,end) columns of each locus;
+ * jit/get_spans.py:11-48).
+ * tq_bootstrap replaces resample_tmp_database (run_inference.py:99-143): loci `lidxs` (host,
+ * i64 [nloci], values in [0,nloci); the reference draws them with rng.choice(nloci, nloci,
+ * replace=True) at :117) are concatenated with their columns shuffled (jit/resample.py:20-64),
+ * IUPAC codes are resolved at random per cell (jit/resolve_ambigs.py:12-36), bases are recoded
+ * 0..3 (:133-136) and the device layout is rebuilt -- the result is the resident replicate, as if
+ * tq_set_data had been called with the resampled tmparr/tmpmap.  The two seeds take the place of
+ * the two rng.integers(2**31) draws (:120,:123); the streams behind them are this engine's own
+ * (counter-based), so replicates are distributed like the reference's, not identical to them.
+ * *out_S receives the replicate's number of sites.
+ * tq_get_data copies the resident replicate back in the reference's layout (tmparr u8 [T,S] with
+ * 0..3 and 78 = missing; tmpmap u32 [S,2] = {locus ordinal, site index}); tq_data_shape gives T,S. */
+int tq_set_source(tq_ctx *ctx, const uint8_t *seqarr, int64_t T, int64_t S0,
+                  const int64_t *spans, int64_t nloci);
+int tq_bootstrap(tq_ctx *ctx, const int64_t *lidxs, int64_t n, uint64_t seed_shuffle,
+                 uint64_t seed_ambig, int64_t *out_S);
+int tq_get_data(tq_ctx *ctx, uint8_t *tmparr, uint32_t *tmpmap);
+int tq_data_shape(tq_ctx *ctx, int64_t *T, int64_t *S);
+
 /* Resolve Q quartets (host buffers, synchronous).
  * Replaces: new_infer_resolved_quartets(tmparr, tmpmap, quartets, subsample_snps)
  *           (resolve_quartets.py:191-265), which returns (quartets, rstat, rscor).

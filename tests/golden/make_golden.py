@@ -177,5 +177,43 @@ def main():
         print(f"wrote {cfg}_slice.npz")
 
 
+def load_reference_jitted():
+    """tetrad/src/jitted.py (self-contained duplicate of tetrad/jit/*), numba.njit = identity.
+    Its np.random.* calls therefore run on NumPy's legacy global RNG, not on numba's stream."""
+    numba = types.ModuleType("numba")
+    numba.njit = lambda f=None, **k: f if f is not None else (lambda g: g)
+    sys.modules.setdefault("numba", numba)
+    spec = importlib.util.spec_from_file_location("ref_jitted", "/root/reference/tetrad/src/jitted.py")
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def make_resample_golden():
+    """Bootstrap-replicate producer (run_inference.py:99-143 pieces).  The span table is
+    deterministic; the two randomised functions are stored as run under NumPy's legacy RNG."""
+    ref = load_reference_jitted()
+    rng = np.random.default_rng(31)
+    T, S = 7, 300
+    alphabet = np.array([65, 67, 71, 84, 78, 82, 75, 83, 89, 87, 77], np.uint8)
+    seqarr = alphabet[rng.choice(len(alphabet), size=(T, S), p=[.2, .2, .2, .2, .08, .02, .02, .02, .02, .02, .02])]
+    tmap = loci_map(S, rng, mean=3)
+    spans = ref.jit_get_spans(tmap.astype(np.int64))
+    nloci = spans.shape[0]
+    lidxs = rng.choice(nloci, nloci, replace=True)
+    tmparr, tmpmap = ref.jit_resample(seqarr, spans, lidxs, seed=12345)
+    resolved = ref.jit_resolve_ambigs(tmparr.copy(), seed=6789)
+    np.savez_compressed(OUT / "resample_T7_S300.npz", seqarr=seqarr, maparr=tmap, spans=spans, lidxs=lidxs,
+                        seed_resample=np.array(12345), seed_ambig=np.array(6789), tmparr=tmparr, tmpmap=tmpmap,
+                        resolved=resolved, numpy_version=np.array(np.__version__))
+    print("wrote resample_T7_S300.npz nloci", nloci, "S_out", tmparr.shape[1])
+    # the toy map of the docstring at jit/get_spans.py:16-18 / deprecated/jitted.py:331-337
+    toy = np.zeros((20, 2), np.int64)
+    toy[:, 0] = [0] * 4 + [1] * 6 + [2] * 1 + [5] * 9
+    toy[:, 1] = np.arange(20)
+    np.savez_compressed(OUT / "spans_toy.npz", maparr=toy, spans=ref.jit_get_spans(toy))
+
+
 if __name__ == "__main__":
     main()
+    make_resample_golden()

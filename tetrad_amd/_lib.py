@@ -27,6 +27,7 @@ FLAG_ZERO_DATA, FLAG_DEGENERATE, FLAG_BAD_INDEX = 1, 2, 4
 #: every symbol include/tetrad_hip.h declares (checked by tests/test_cabi_symbols.py)
 SYMBOLS = [
     "tq_create", "tq_destroy", "tq_last_error", "tq_set_data", "tq_resolve",
+    "tq_set_source", "tq_bootstrap", "tq_get_data", "tq_data_shape",
     "tq_resolve_dev", "tq_resolve_range_dev", "tq_unrank_dev", "tq_resolve_debug",
     "tq_timing_enable", "tq_timing_read", "tq_timing_read_split", "tq_set_option", "tq_device_info",
 ]
@@ -81,6 +82,14 @@ def load() -> ctypes.CDLL:
     lib.tq_last_error.restype = c.c_char_p
     lib.tq_set_data.argtypes = [vp, vp, i64, i64, vp, i64]
     lib.tq_set_data.restype = i32
+    lib.tq_set_source.argtypes = [vp, vp, i64, i64, vp, i64]
+    lib.tq_set_source.restype = i32
+    lib.tq_bootstrap.argtypes = [vp, vp, i64, c.c_uint64, c.c_uint64, c.POINTER(i64)]
+    lib.tq_bootstrap.restype = i32
+    lib.tq_get_data.argtypes = [vp, vp, vp]
+    lib.tq_get_data.restype = i32
+    lib.tq_data_shape.argtypes = [vp, c.POINTER(i64), c.POINTER(i64)]
+    lib.tq_data_shape.restype = i32
     lib.tq_resolve.argtypes = [vp, vp, i64, i32, vp, vp, vp]
     lib.tq_resolve.restype = i32
     lib.tq_resolve_dev.argtypes = [vp, vp, i64, i32, vp, vp, vp, vp]

@@ -1208,6 +1208,147 @@ tq_score_kernel(const double *__restrict__ sv, const uint32_t *__restrict__ nsnp
     if (out.flags) out.flags[q] = (uint8_t)fl;
 }
 
+// ====================================================================================
+// Bootstrap replicate built on the device.
+// Reference: resample_tmp_database (tetrad/src/run_inference.py:99-143) = jit_resample
+// (tetrad/jit/resample.py:20-64: loci resampled with replacement, columns shuffled inside each
+// locus, locus column = ordinal of the resampled locus) + jit_resolve_ambigs
+// (tetrad/jit/resolve_ambigs.py:12-36: every IUPAC two-base code resolved to one of its two
+// bases with probability 1/2, per cell) + the ACGT -> 0..3 recode (:133-136).  Here the three
+// steps and the layout build are fused: the replicate never exists on the host and nothing is
+// written back to HDF5.  Random streams: the reference uses numba's Mersenne twister seeded from
+// the project Generator; this engine uses counter-based hashes of (seed, position).  Only the
+// distribution can match (RNG-stream parity is unpinned); the host keeps the
+// reference's draw order on the project Generator (tetrad_amd/bootstrap.py).
+// ====================================================================================
+__device__ __forceinline__ uint64_t mix64(uint64_t x)     // splitmix64 finaliser
+{
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+
+// widths[i] = spans[lidx[i]][1] - spans[lidx[i]][0]
+__global__ void tq_boot_width_kernel(const int64_t *__restrict__ spans, const int64_t *__restrict__ lidxs, int64_t n,
+                                     int64_t nloci, uint32_t *__restrict__ widths)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int64_t l = lidxs[i];
+    if (l < 0 || l >= nloci) l = 0;
+    widths[i] = (uint32_t)(spans[2 * l + 1] - spans[2 * l]);
+}
+
+// one thread per resampled locus: Fisher-Yates shuffle of its columns (resample.py:49-50);
+// src_col[s] = source column of output site s, site_locus[s] = ordinal of its resampled locus (:58)
+__global__ void tq_boot_perm_kernel(const int64_t *__restrict__ spans, const int64_t *__restrict__ lidxs,
+                                    const uint32_t *__restrict__ offsets, int64_t n, int64_t nloci, uint64_t seed,
+                                    uint32_t *__restrict__ src_col, uint32_t *__restrict__ site_locus)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int64_t l = lidxs[i];
+    if (l < 0 || l >= nloci) l = 0;
+    const uint32_t start = (uint32_t)spans[2 * l];
+    const uint32_t w = (uint32_t)(spans[2 * l + 1] - spans[2 * l]);
+    uint32_t *p = src_col + offsets[i];
+    uint32_t *loc = site_locus + offsets[i];
+    for (uint32_t j = 0; j < w; ++j) {
+        p[j] = start + j;
+        loc[j] = (uint32_t)i;
+    }
+    uint64_t state = mix64(seed ^ ((uint64_t)i * 0xD1342543DE82EF95ull));
+    for (uint32_t j = w; j > 1; --j) {
+        state = mix64(state);
+        // unbiased enough for j << 2^32: multiply-high of a 32-bit draw
+        const uint32_t r = (uint32_t)(((state >> 32) * (uint64_t)j) >> 32);
+        const uint32_t tmp = p[j - 1];
+        p[j - 1] = p[r];
+        p[r] = tmp;
+    }
+}
+
+// one thread per 32-site word of one taxon row: gather + ambiguity resolution + recode + layout
+__global__ void tq_boot_build_kernel(const uint8_t *__restrict__ seqarr, int64_t S0,
+                                     const uint32_t *__restrict__ src_col, const uint32_t *__restrict__ site_locus,
+                                     int64_t S, int64_t Sp, int64_t W, int32_t T, uint64_t seed,
+                                     uint8_t *__restrict__ rows, uint4 *__restrict__ planes)
+{
+    int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= (int64_t)T * W) return;
+    const int64_t t = gid / W, w = gid - t * W;
+    uint8_t *dst = rows + t * Sp + w * 32;
+    uint32_t mm = 0, b0 = 0, b1 = 0, rb = 0;
+    for (int i = 0; i < 32; ++i) {
+        const int64_t s = w * 32 + i;
+        uint8_t code = 0;
+        bool missing = true;
+        if (s < S) {
+            uint8_t v = seqarr[t * S0 + src_col[s]];
+            // IUPAC two-base codes (utils.py:14-21): R->G/A K->G/T S->G/C Y->T/C W->T/A M->C/A
+            const bool coin = (mix64(seed ^ ((uint64_t)t * 0x9E3779B97F4A7C15ull) ^ (uint64_t)s * 0xC2B2AE3D27D4EB4Full) >> 63) != 0;
+            switch (v) {
+            case 82: v = coin ? 71 : 65; break;
+            case 75: v = coin ? 71 : 84; break;
+            case 83: v = coin ? 71 : 67; break;
+            case 89: v = coin ? 84 : 67; break;
+            case 87: v = coin ? 84 : 65; break;
+            case 77: v = coin ? 67 : 65; break;
+            default: break;
+            }
+            // run_inference.py:133-136: A,C,G,T -> 0,1,2,3 ; everything else stays a byte > 3 (missing)
+            if (v == 65) { code = 0; missing = false; }
+            else if (v == 67) { code = 1; missing = false; }
+            else if (v == 71) { code = 2; missing = false; }
+            else if (v == 84) { code = 3; missing = false; }
+            else if (v <= 3) { code = v; missing = false; }       // already recoded input
+            const bool beg = (s == 0) || (site_locus[s] != site_locus[s - 1]);
+            rb |= (uint32_t)beg << i;
+        }
+        dst[i] = code;
+        mm |= (uint32_t)missing << i;
+        b0 |= (uint32_t)(code & 1) << i;
+        b1 |= (uint32_t)((code >> 1) & 1) << i;
+    }
+    planes[t * W + w] = make_uint4(mm, b0, b1, rb);
+}
+
+// replicate currently on the device -> the reference's tmparr (0..3, 78) / tmpmap layout
+__global__ void tq_export_kernel(const uint8_t *__restrict__ rows, const uint4 *__restrict__ planes, int64_t S,
+                                 int64_t Sp, int64_t W, int32_t T, uint8_t *__restrict__ tmparr,
+                                 uint32_t *__restrict__ tmpmap)
+{
+    int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= (int64_t)T * S) return;
+    const int64_t t = gid / S, s = gid - t * S;
+    const uint32_t miss = planes[t * W + (s >> 5)].x;
+    tmparr[gid] = ((miss >> (s & 31)) & 1u) ? (uint8_t)78 : rows[t * Sp + s];
+    if (t == 0) tmpmap[2 * s + 1] = (uint32_t)s;
+}
+
+// locus ordinals from the run-begin bits (inclusive prefix count - 1), one thread per 32-site word
+__global__ void tq_export_runcount_kernel(const uint4 *__restrict__ planes, int64_t W, uint32_t *__restrict__ cnt)
+{
+    int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (w < W) cnt[w] = (uint32_t)__popc(planes[w].w);
+}
+
+__global__ void tq_export_locus_kernel(const uint4 *__restrict__ planes, const uint32_t *__restrict__ base, int64_t S,
+                                       int64_t W, uint32_t *__restrict__ tmpmap)
+{
+    int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= W) return;
+    const uint32_t rb = planes[w].w;
+    uint32_t ord = base[w];                  // run-begins before this word
+    for (int i = 0; i < 32; ++i) {
+        const int64_t s = w * 32 + i;
+        if (s >= S) break;
+        ord += (rb >> i) & 1u;
+        tmpmap[2 * s] = ord - 1u;
+    }
+}
+
 }  // namespace
 
 // ======================================================================================
@@ -1223,6 +1364,16 @@ struct tq_ctx {
     uint4 *d_planes = nullptr;      // [T][W] {miss, p0, p1, runbeg}
     bool have_data = false;
     bool locus_runs_ok = false;
+    int64_t data_capacity = 0;      // allocated Sp (rows/planes are re-used by bootstrap replicates)
+    // bootstrap source (tq_set_source): ASCII seqarr [T][S0], spans i64 [nloci][2]
+    uint8_t *d_seqarr = nullptr;
+    int64_t *d_spans = nullptr;
+    int64_t src_T = 0, src_S0 = 0, nloci = 0, max_width = 0;
+    int64_t *d_lidxs = nullptr;     // [nloci]
+    uint32_t *d_boot = nullptr;     // widths/offsets [nloci+1] | src_col [cap] | site_locus [cap]
+    int64_t boot_cap = 0;
+    void *d_boot_tmp = nullptr;
+    size_t boot_tmp_bytes = 0;
     // scratch for the host-buffer API
     void *d_scratch = nullptr;
     size_t scratch_bytes = 0;
@@ -1283,6 +1434,23 @@ void free_data(tq_ctx *ctx)
     ctx->d_rows = nullptr;
     ctx->d_planes = nullptr;
     ctx->have_data = false;
+    ctx->data_capacity = 0;
+}
+
+void free_source(tq_ctx *ctx)
+{
+    if (ctx->d_seqarr) (void)hipFree(ctx->d_seqarr);
+    if (ctx->d_spans) (void)hipFree(ctx->d_spans);
+    if (ctx->d_lidxs) (void)hipFree(ctx->d_lidxs);
+    if (ctx->d_boot) (void)hipFree(ctx->d_boot);
+    if (ctx->d_boot_tmp) (void)hipFree(ctx->d_boot_tmp);
+    ctx->d_seqarr = nullptr;
+    ctx->d_spans = nullptr;
+    ctx->d_lidxs = nullptr;
+    ctx->d_boot = nullptr;
+    ctx->d_boot_tmp = nullptr;
+    ctx->boot_cap = 0;
+    ctx->nloci = 0;
 }
 
 int ensure_scratch(tq_ctx *ctx, size_t bytes)
@@ -1568,6 +1736,7 @@ void tq_destroy(tq_ctx *ctx)
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     free_data(ctx);
+    free_source(ctx);
     if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
     if (ctx->d_cm) (void)hipFree(ctx->d_cm);
     if (ctx->d_sort) (void)hipFree(ctx->d_sort);
@@ -1615,6 +1784,7 @@ int tq_set_data(tq_ctx *ctx, const uint8_t *tmparr, int64_t T, int64_t S, const 
     const int64_t Sp = (int64_t)align_up((size_t)S, TILE);
     const int64_t W = Sp / 32;
     ctx->T = T; ctx->S = S; ctx->Sp = Sp; ctx->W = W;
+    ctx->data_capacity = Sp;
     uint8_t *d_raw = nullptr;
     uint32_t *d_loc = nullptr;
     TQ_HIP(ctx, hipMalloc((void **)&ctx->d_rows, (size_t)(T * Sp)));
@@ -1828,6 +1998,148 @@ int tq_set_option(tq_ctx *ctx, const char *name, int64_t value)
         return ctx->phases;
     }
     return fail(ctx, TQ_ERR_INVALID_ARG, "unknown option '%s'", name);
+}
+
+int tq_set_source(tq_ctx *ctx, const uint8_t *seqarr, int64_t T, int64_t S0, const int64_t *spans, int64_t nloci)
+{
+    if (!ctx) return TQ_ERR_INVALID_ARG;
+    if (!seqarr || !spans) return fail(ctx, TQ_ERR_INVALID_ARG, "tq_set_source: NULL pointer");
+    if (T < 1 || S0 < 1 || nloci < 1 || T > 0x7FFFFFFF)
+        return fail(ctx, TQ_ERR_INVALID_ARG, "tq_set_source: bad shape T=%lld S0=%lld nloci=%lld", (long long)T,
+                    (long long)S0, (long long)nloci);
+    int64_t maxw = 0;
+    for (int64_t i = 0; i < nloci; ++i) {
+        const int64_t a = spans[2 * i], b = spans[2 * i + 1];
+        if (a < 0 || b <= a || b > S0)
+            return fail(ctx, TQ_ERR_INVALID_ARG, "tq_set_source: span %lld = [%lld,%lld) outside [0,%lld)",
+                        (long long)i, (long long)a, (long long)b, (long long)S0);
+        if (b - a > maxw) maxw = b - a;
+    }
+    TQ_HIP(ctx, hipSetDevice(ctx->device));
+    free_source(ctx);
+    TQ_HIP(ctx, hipMalloc((void **)&ctx->d_seqarr, (size_t)(T * S0)));
+    TQ_HIP(ctx, hipMalloc((void **)&ctx->d_spans, (size_t)nloci * 16));
+    TQ_HIP(ctx, hipMalloc((void **)&ctx->d_lidxs, (size_t)nloci * 8));
+    TQ_HIP(ctx, hipMemcpy(ctx->d_seqarr, seqarr, (size_t)(T * S0), hipMemcpyHostToDevice));
+    TQ_HIP(ctx, hipMemcpy(ctx->d_spans, spans, (size_t)nloci * 16, hipMemcpyHostToDevice));
+    ctx->src_T = T;
+    ctx->src_S0 = S0;
+    ctx->nloci = nloci;
+    ctx->max_width = maxw;
+    return TQ_OK;
+}
+
+int tq_bootstrap(tq_ctx *ctx, const int64_t *lidxs, int64_t n, uint64_t seed_shuffle, uint64_t seed_ambig,
+                 int64_t *out_S)
+{
+    if (!ctx) return TQ_ERR_INVALID_ARG;
+    if (!ctx->d_seqarr) return fail(ctx, TQ_ERR_NO_DATA, "tq_set_source has not been called");
+    if (!lidxs || n != ctx->nloci)
+        return fail(ctx, TQ_ERR_INVALID_ARG, "tq_bootstrap: lidxs must hold nloci=%lld locus indices", (long long)ctx->nloci);
+    int64_t S = 0;
+    for (int64_t i = 0; i < n; ++i)
+        if (lidxs[i] < 0 || lidxs[i] >= ctx->nloci)
+            return fail(ctx, TQ_ERR_INVALID_ARG, "tq_bootstrap: locus index %lld out of range", (long long)lidxs[i]);
+    TQ_HIP(ctx, hipSetDevice(ctx->device));
+    const int64_t T = ctx->src_T;
+    // worst-case replicate length; buffers grow only
+    const int64_t cap = n * ctx->max_width;
+    if (cap > ctx->boot_cap) {
+        if (ctx->d_boot) (void)hipFree(ctx->d_boot);
+        if (ctx->d_boot_tmp) (void)hipFree(ctx->d_boot_tmp);
+        ctx->d_boot = nullptr;
+        ctx->d_boot_tmp = nullptr;
+        ctx->boot_cap = 0;
+        TQ_HIP(ctx, hipMalloc((void **)&ctx->d_boot, (size_t)(2 * (n + 1) + 2 * cap) * sizeof(uint32_t)));
+        size_t tmp = 0;
+        uint32_t *u = ctx->d_boot;
+        TQ_HIP(ctx, hipcub::DeviceScan::ExclusiveSum(nullptr, tmp, u, u, (int)(n + 1)));
+        size_t tmp2 = 0;
+        TQ_HIP(ctx, hipcub::DeviceScan::ExclusiveSum(nullptr, tmp2, u, u, (int)(cap / 32 + 2)));
+        if (tmp2 > tmp) tmp = tmp2;
+        TQ_HIP(ctx, hipMalloc(&ctx->d_boot_tmp, tmp ? tmp : 16));
+        ctx->boot_tmp_bytes = tmp;
+        ctx->boot_cap = cap;
+    }
+    uint32_t *widths = ctx->d_boot, *offsets = widths + (n + 1);
+    uint32_t *src_col = offsets + (n + 1), *site_locus = src_col + ctx->boot_cap;
+    TQ_HIP(ctx, hipMemcpy(ctx->d_lidxs, lidxs, (size_t)n * 8, hipMemcpyHostToDevice));
+    TQ_HIP(ctx, hipMemset(widths + n, 0, sizeof(uint32_t)));
+    hipLaunchKernelGGL(tq_boot_width_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, ctx->d_spans,
+                       ctx->d_lidxs, n, ctx->nloci, widths);
+    size_t tmp = ctx->boot_tmp_bytes;
+    TQ_HIP(ctx, hipcub::DeviceScan::ExclusiveSum(ctx->d_boot_tmp, tmp, widths, offsets, (int)(n + 1)));
+    uint32_t total = 0;
+    TQ_HIP(ctx, hipMemcpy(&total, offsets + n, sizeof(uint32_t), hipMemcpyDeviceToHost));
+    S = (int64_t)total;
+    if (S < 1 || S > ctx->boot_cap) return fail(ctx, TQ_ERR_HIP, "tq_bootstrap: inconsistent replicate length %lld", (long long)S);
+    const int64_t Sp = (int64_t)align_up((size_t)S, TILE);
+    const int64_t W = Sp / 32;
+    if (Sp > ctx->data_capacity || T != ctx->T) {
+        free_data(ctx);
+        const int64_t capSp = (int64_t)align_up((size_t)(Sp + Sp / 8), TILE);   // head-room: replicate lengths vary
+        TQ_HIP(ctx, hipMalloc((void **)&ctx->d_rows, (size_t)(T * capSp)));
+        TQ_HIP(ctx, hipMalloc((void **)&ctx->d_planes, (size_t)(T * (capSp / 32)) * sizeof(uint4)));
+        ctx->data_capacity = capSp;
+    }
+    hipLaunchKernelGGL(tq_boot_perm_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, ctx->d_spans,
+                       ctx->d_lidxs, offsets, n, ctx->nloci, seed_shuffle, src_col, site_locus);
+    const int64_t nw = T * W;
+    hipLaunchKernelGGL(tq_boot_build_kernel, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, 0, ctx->d_seqarr,
+                       ctx->src_S0, src_col, site_locus, S, Sp, W, (int32_t)T, seed_ambig, ctx->d_rows, ctx->d_planes);
+    TQ_HIP(ctx, hipGetLastError());
+    TQ_HIP(ctx, hipDeviceSynchronize());
+    ctx->T = T;
+    ctx->S = S;
+    ctx->Sp = Sp;
+    ctx->W = W;
+    ctx->have_data = true;
+    ctx->locus_runs_ok = true;          // locus ids are the ordinals 0..n-1, one run each
+    if (out_S) *out_S = S;
+    return TQ_OK;
+}
+
+int tq_get_data(tq_ctx *ctx, uint8_t *tmparr, uint32_t *tmpmap)
+{
+    if (!ctx) return TQ_ERR_INVALID_ARG;
+    if (!ctx->have_data) return fail(ctx, TQ_ERR_NO_DATA, "no replicate on the device");
+    if (!tmparr || !tmpmap) return fail(ctx, TQ_ERR_INVALID_ARG, "tq_get_data: NULL pointer");
+    TQ_HIP(ctx, hipSetDevice(ctx->device));
+    const int64_t T = ctx->T, S = ctx->S, W = ctx->W;
+    const size_t bytes = align_up((size_t)(T * S), 256) + align_up((size_t)S * 8, 256) + align_up((size_t)(W + 1) * 8, 256);
+    int rc = ensure_scratch(ctx, bytes);
+    if (rc) return rc;
+    uint8_t *d_arr = (uint8_t *)ctx->d_scratch;
+    uint32_t *d_map = (uint32_t *)((char *)ctx->d_scratch + align_up((size_t)(T * S), 256));
+    uint32_t *d_cnt = (uint32_t *)((char *)d_map + align_up((size_t)S * 8, 256));
+    uint32_t *d_base = d_cnt + (W + 1);
+    hipLaunchKernelGGL(tq_export_kernel, dim3((unsigned)((T * S + 255) / 256)), dim3(256), 0, 0, ctx->d_rows,
+                       ctx->d_planes, S, ctx->Sp, W, (int32_t)T, d_arr, d_map);
+    hipLaunchKernelGGL(tq_export_runcount_kernel, dim3((unsigned)((W + 255) / 256)), dim3(256), 0, 0, ctx->d_planes, W,
+                       d_cnt);
+    size_t tmp = 0;
+    TQ_HIP(ctx, hipcub::DeviceScan::ExclusiveSum(nullptr, tmp, d_cnt, d_base, (int)W));
+    void *d_tmp = nullptr;
+    TQ_HIP(ctx, hipMalloc(&d_tmp, tmp ? tmp : 16));
+    hipError_t e = hipcub::DeviceScan::ExclusiveSum(d_tmp, tmp, d_cnt, d_base, (int)W);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(tq_export_locus_kernel, dim3((unsigned)((W + 255) / 256)), dim3(256), 0, 0, ctx->d_planes,
+                           (const uint32_t *)d_base, S, W, d_map);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpy(tmparr, d_arr, (size_t)(T * S), hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(tmpmap, d_map, (size_t)S * 8, hipMemcpyDeviceToHost);
+    (void)hipFree(d_tmp);
+    if (e != hipSuccess) return fail(ctx, TQ_ERR_HIP, "tq_get_data: %s", hipGetErrorString(e));
+    return TQ_OK;
+}
+
+int tq_data_shape(tq_ctx *ctx, int64_t *T, int64_t *S)
+{
+    if (!ctx) return TQ_ERR_INVALID_ARG;
+    if (T) *T = ctx->have_data ? ctx->T : 0;
+    if (S) *S = ctx->have_data ? ctx->S : 0;
+    return TQ_OK;
 }
 
 int tq_device_info(tq_ctx *ctx, int32_t *num_cu, int32_t *waves_per_cu, int64_t *row_pitch)

@@ -72,6 +72,35 @@ class QuartetEngine:
         self._check(self._lib.tq_set_data(self._h, _ptr(tmparr), T, S, _ptr(tm), stride))
         self.T, self.S = T, S
 
+    # -- bootstrap replicates on the device -------------------------------------
+    def set_source(self, seqarr: np.ndarray, spans: np.ndarray):
+        """seqarr u8[T,S0] (ASCII, IUPAC codes allowed); spans i64[nloci,2] ([start,end) per locus)."""
+        seqarr = np.ascontiguousarray(seqarr, dtype=np.uint8)
+        spans = np.ascontiguousarray(spans, dtype=np.int64).reshape(-1, 2)
+        T, S0 = seqarr.shape
+        self._check(self._lib.tq_set_source(self._h, _ptr(seqarr), T, S0, _ptr(spans), spans.shape[0]))
+        self.nloci = spans.shape[0]
+
+    def bootstrap(self, lidxs: np.ndarray, seed_shuffle: int, seed_ambig: int) -> int:
+        """Build the replicate for resampled loci `lidxs` on the device; returns its number of sites."""
+        lidxs = np.ascontiguousarray(lidxs, dtype=np.int64)
+        S = ctypes.c_int64()
+        self._check(self._lib.tq_bootstrap(self._h, _ptr(lidxs), lidxs.shape[0], int(seed_shuffle), int(seed_ambig),
+                                           ctypes.byref(S)))
+        T = ctypes.c_int64()
+        self._check(self._lib.tq_data_shape(self._h, ctypes.byref(T), None))
+        self.T, self.S = T.value, S.value
+        return S.value
+
+    def get_data(self):
+        """Resident replicate in the reference layout: (tmparr u8[T,S] 0..3/78, tmpmap u32[S,2])."""
+        T, S = ctypes.c_int64(), ctypes.c_int64()
+        self._check(self._lib.tq_data_shape(self._h, ctypes.byref(T), ctypes.byref(S)))
+        tmparr = np.zeros((T.value, S.value), np.uint8)
+        tmpmap = np.zeros((S.value, 2), np.uint32)
+        self._check(self._lib.tq_get_data(self._h, _ptr(tmparr), _ptr(tmpmap)))
+        return tmparr, tmpmap
+
     def set_option(self, name: str, value: int) -> int:
         rc = self._lib.tq_set_option(self._h, name.encode(), int(value))
         if rc < 0:

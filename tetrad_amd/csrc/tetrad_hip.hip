@@ -8,7 +8,8 @@
 // quartet during the singular-value stage.
 //
 // Data layout in HBM (built once per replicate by tq_set_data):
-//   rows   u8   [T][Sp]  base code 0..3 per site, missing/pad -> 0    (Sp = S rounded up to 2048)
+//   rows   u8   [T][Sp]  base code 0..3 per site, missing/pad -> 0    (Sp = S rounded up to 2048;
+//                        inside each 2048-site step the bytes are stored in two 1 KiB panels, row_offset())
 //   planes u32x4[T][W]   per 32 sites: {missing bits, base bit 0, base bit 1, run-begin bits}
 //                        (W = Sp/32; run-begin = site starts a new locus run, same for every row,
 //                        replicated so that one 16-byte load brings everything a lane needs)
@@ -65,6 +66,15 @@ struct DevData {
     int32_t ntiles;     // Sp / TILE
 };
 
+// Byte offset of site s inside a row.  A 2048-site step is stored as two 1 KiB panels: panel 0
+// holds sites 0-15 of every lane's 32-site group, panel 1 holds sites 16-31, so each of the two
+// 16-byte loads a lane issues per row is part of one fully contiguous 1 KiB wave access.
+__host__ __device__ __forceinline__ int64_t row_offset(int64_t s)
+{
+    const int64_t tile = s >> 11, r = s & 2047, lane = r >> 5, k = r & 31;
+    return (tile << 11) + ((k >> 4) << 10) + (lane << 4) + (k & 15);
+}
+
 struct OutPtrs {
     uint32_t *rstat;    // [Q,2]
     double *rscor;      // [Q,3]
@@ -85,14 +95,14 @@ __global__ void tq_prepare_rows(const uint8_t *__restrict__ raw, const uint32_t 
     if (gid >= (int64_t)T * W) return;
     int64_t t = gid / W, w = gid - t * W;
     const uint8_t *src = raw + t * S + w * 32;
-    uint8_t *dst = rows + t * Sp + w * 32;
+    uint8_t *dst = rows + t * Sp;
     uint32_t mm = 0, b0 = 0, b1 = 0, rb = 0;
     for (int i = 0; i < 32; ++i) {
         int64_t s = w * 32 + i;
         uint8_t v = (s < S) ? src[i] : (uint8_t)0xFF;
         bool missing = v > 3;
         uint8_t code = missing ? (uint8_t)0 : v;
-        dst[i] = code;
+        dst[row_offset(s)] = code;
         mm |= (uint32_t)missing << i;
         b0 |= (uint32_t)(code & 1) << i;
         b1 |= (uint32_t)((code >> 1) & 1) << i;
@@ -160,15 +170,15 @@ struct TileRegs {
 __device__ __forceinline__ void load_tile(TileRegs &r, const DevData &d, const uint32_t (&q)[4], int tile,
                                           int lane)
 {
-    const int64_t boff = (int64_t)tile * TILE + lane * SITES_PER_LANE;
+    const int64_t boff = (int64_t)tile * TILE + lane * 16;            // panel layout: see row_offset
     const uint4 *pa = reinterpret_cast<const uint4 *>(d.rows + (int64_t)q[0] * d.pitch + boff);
     const uint4 *pb = reinterpret_cast<const uint4 *>(d.rows + (int64_t)q[1] * d.pitch + boff);
     const uint4 *pc = reinterpret_cast<const uint4 *>(d.rows + (int64_t)q[2] * d.pitch + boff);
     const uint4 *pd = reinterpret_cast<const uint4 *>(d.rows + (int64_t)q[3] * d.pitch + boff);
-    r.a0 = pa[0]; r.a1 = pa[1];
-    r.b0 = pb[0]; r.b1 = pb[1];
-    r.c0 = pc[0]; r.c1 = pc[1];
-    r.d0 = pd[0]; r.d1 = pd[1];
+    r.a0 = pa[0]; r.a1 = pa[64];
+    r.b0 = pb[0]; r.b1 = pb[64];
+    r.c0 = pc[0]; r.c1 = pc[64];
+    r.d0 = pd[0]; r.d1 = pd[64];
     const int64_t woff = (int64_t)tile * WAVE + lane;
     r.pa = d.planes[(int64_t)q[0] * d.W + woff];
     r.pb = d.planes[(int64_t)q[1] * d.W + woff];
@@ -373,11 +383,11 @@ struct OwnRegs {
 
 __device__ __forceinline__ void load_own(OwnRegs &r, const DevData &d, uint32_t qc, uint32_t qd, int tile, int lane)
 {
-    const int64_t boff = (int64_t)tile * TILE + lane * SITES_PER_LANE;
+    const int64_t boff = (int64_t)tile * TILE + lane * 16;
     const uint4 *pc = reinterpret_cast<const uint4 *>(d.rows + (int64_t)qc * d.pitch + boff);
     const uint4 *pd = reinterpret_cast<const uint4 *>(d.rows + (int64_t)qd * d.pitch + boff);
-    r.c0 = pc[0]; r.c1 = pc[1];
-    r.d0 = pd[0]; r.d1 = pd[1];
+    r.c0 = pc[0]; r.c1 = pc[64];
+    r.d0 = pd[0]; r.d1 = pd[64];
     const int64_t woff = (int64_t)tile * WAVE + lane;
     r.pc = d.planes[(int64_t)qc * d.W + woff];
     r.pd = d.planes[(int64_t)qd * d.W + woff];
@@ -439,9 +449,7 @@ tq_scan_wg_kernel(DevData d, const uint32_t *__restrict__ quartets, const uint32
         const uint32_t qc = work ? q[2] : 0, qd = work ? q[3] : 0;
 
         // prologue: step 0 into buffer 0
-        // LDS slot of piece p: the two 16-byte halves of a lane's 32 row bytes go to separate
-        // 1 KiB panels so that lanes read consecutive 16-byte slots (conflict-free ds_read_b128)
-        const int slot = tid < 256 ? ((tid & 128) | ((tid & 1) << 6) | ((tid & 127) >> 1)) : tid;
+        const int slot = tid;     // rows are stored in panels already (row_offset), so piece p is slot p
         if (tid < SHARED_PIECES) shared_ab[0][slot] = load_shared_piece(d, la, lb, 0, tid);
         OwnRegs A, B;
         load_own(A, d, qc, qd, 0, lane);
@@ -459,11 +467,11 @@ tq_scan_wg_kernel(DevData d, const uint32_t *__restrict__ quartets, const uint32
                 r.pa = buf[256 + lane];
                 r.pb = buf[320 + lane];
             } else if (work) {                               // group boundary: private rows a and b
-                const int64_t boff = (int64_t)t * TILE + lane * SITES_PER_LANE;
+                const int64_t boff = (int64_t)t * TILE + lane * 16;
                 const uint4 *pa = reinterpret_cast<const uint4 *>(d.rows + (int64_t)q[0] * d.pitch + boff);
                 const uint4 *pb = reinterpret_cast<const uint4 *>(d.rows + (int64_t)q[1] * d.pitch + boff);
-                r.a0 = pa[0]; r.a1 = pa[1];
-                r.b0 = pb[0]; r.b1 = pb[1];
+                r.a0 = pa[0]; r.a1 = pa[64];
+                r.b0 = pb[0]; r.b1 = pb[64];
                 const int64_t woff = (int64_t)t * WAVE + lane;
                 r.pa = d.planes[(int64_t)q[0] * d.W + woff];
                 r.pb = d.planes[(int64_t)q[1] * d.W + woff];
@@ -873,7 +881,7 @@ __device__ __forceinline__ double sqrt_nr(double x)     // x >= 0, full precisio
 
 // de layout: f64 [3*Q][32]: d[0..15] then e[0..15] with e[0] = 0 (e[i] couples columns i-1, i)
 template <bool DEBUG>
-__global__ void __launch_bounds__(WAVE)
+__global__ void __launch_bounds__(WAVE, 2)
 tq_bidiag_kernel(const uint32_t *__restrict__ cm, int64_t Q, double *__restrict__ de,
                  uint32_t *__restrict__ nsnps_out, uint32_t *__restrict__ cmats_dbg)
 {
@@ -922,8 +930,11 @@ tq_bidiag_kernel(const uint32_t *__restrict__ cm, int64_t Q, double *__restrict_
                     }
                 }
             }
-            double dd[16], ee[16];
-            ee[0] = 0.0;
+            // d[K] / e[K] are stored as soon as they are known (keeping 32 more f64 live would cost
+            // the kernel its second wave per SIMD)
+            double *dout = de + (myq * 3 + t) * 32;
+            const bool writer = (c == 0) && (myq < Q);
+            if (writer) dout[16] = 0.0;
             static_for<0, 16>([&](auto kc) {
                 constexpr int K = decltype(kc)::value;
                 // ---- left reflector: zero column K below the diagonal ----
@@ -941,7 +952,7 @@ tq_bidiag_kernel(const uint32_t *__restrict__ cm, int64_t Q, double *__restrict_
                     v[K] = x0 - alpha;
                     const double den = fma(-alpha, x0, n2);      // = |v|^2 / 2 > 0 unless the column is zero
                     const double beta = n2 > 0.0 ? rcp_nr<2>(den) : 0.0;
-                    dd[K] = alpha;
+                    if (writer) dout[K] = alpha;
 #pragma unroll
                     for (int s = so; s < 4; ++s) {
                         double w = 0.0;
@@ -970,7 +981,7 @@ tq_bidiag_kernel(const uint32_t *__restrict__ cm, int64_t Q, double *__restrict_
                     const double den = fma(-alpha, x0, n2);
                     const double beta = n2 > 0.0 ? rcp_nr<2>(den) : 0.0;
                     if (c == c1) y[s1] = x0 - alpha;
-                    ee[K1] = alpha;
+                    if (writer) dout[16 + K1] = alpha;
 #pragma unroll
                     for (int i = K1; i < 16; ++i) {
                         double q = 0.0;
@@ -981,17 +992,10 @@ tq_bidiag_kernel(const uint32_t *__restrict__ cm, int64_t Q, double *__restrict_
                         for (int s = sb; s < 4; ++s) a[s][i] = fma(-tt, y[s], a[s][i]);
                     }
                 } else if constexpr (K == 14) {
-                    ee[15] = quad_bcast<3>(a[3][14]);            // column 15 lives in slot 3 of lane 3
+                    const double e15 = quad_bcast<3>(a[3][14]);  // column 15 lives in slot 3 of lane 3
+                    if (writer) dout[31] = e15;
                 }
             });
-            if (c == 0 && myq < Q) {
-                double *o = de + (myq * 3 + t) * 32;
-#pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    o[i] = dd[i];
-                    o[16 + i] = ee[i];
-                }
-            }
         }
         __syncthreads();
     }
@@ -1278,7 +1282,7 @@ __global__ void tq_boot_build_kernel(const uint8_t *__restrict__ seqarr, int64_t
     int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= (int64_t)T * W) return;
     const int64_t t = gid / W, w = gid - t * W;
-    uint8_t *dst = rows + t * Sp + w * 32;
+    uint8_t *dst = rows + t * Sp;
     uint32_t mm = 0, b0 = 0, b1 = 0, rb = 0;
     for (int i = 0; i < 32; ++i) {
         const int64_t s = w * 32 + i;
@@ -1306,7 +1310,7 @@ __global__ void tq_boot_build_kernel(const uint8_t *__restrict__ seqarr, int64_t
             const bool beg = (s == 0) || (site_locus[s] != site_locus[s - 1]);
             rb |= (uint32_t)beg << i;
         }
-        dst[i] = code;
+        dst[row_offset(s)] = code;
         mm |= (uint32_t)missing << i;
         b0 |= (uint32_t)(code & 1) << i;
         b1 |= (uint32_t)((code >> 1) & 1) << i;
@@ -1323,7 +1327,7 @@ __global__ void tq_export_kernel(const uint8_t *__restrict__ rows, const uint4 *
     if (gid >= (int64_t)T * S) return;
     const int64_t t = gid / S, s = gid - t * S;
     const uint32_t miss = planes[t * W + (s >> 5)].x;
-    tmparr[gid] = ((miss >> (s & 31)) & 1u) ? (uint8_t)78 : rows[t * Sp + s];
+    tmparr[gid] = ((miss >> (s & 31)) & 1u) ? (uint8_t)78 : rows[t * Sp + row_offset(s)];
     if (t == 0) tmpmap[2 * s + 1] = (uint32_t)s;
 }
 

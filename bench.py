@@ -144,24 +144,40 @@ def main():
     eng.set_data(tmparr, tmpmap)
 
     d_q = torch.from_numpy(quartets.astype(np.int32)).to(dev)
-    d_rstat = torch.zeros((Q, 2), dtype=torch.int32, device=dev)
-    d_rscor = torch.zeros((Q, 3), dtype=torch.float64, device=dev)
+    # two sets of output buffers: for N > 1 the all-gather of pass i runs (on RCCL's stream) while
+    # the kernels of pass i+1 write the other set
+    nbuf = 2 if world > 1 else 1
+    d_rstats = [torch.zeros((Q, 2), dtype=torch.int32, device=dev) for _ in range(nbuf)]
+    d_rscors = [torch.zeros((Q, 3), dtype=torch.float64, device=dev) for _ in range(nbuf)]
     d_flags = torch.zeros(Q, dtype=torch.uint8, device=dev)
     gdev = dev if args.backend == "nccl" else torch.device("cpu")
     if world > 1:
-        g_rstat = torch.zeros((world * Q, 2), dtype=torch.int32, device=gdev)
-        g_rscor = torch.zeros((world * Q, 3), dtype=torch.float64, device=gdev)
+        g_rstats = [torch.zeros((world * Q, 2), dtype=torch.int32, device=gdev) for _ in range(nbuf)]
+        g_rscors = [torch.zeros((world * Q, 3), dtype=torch.float64, device=gdev) for _ in range(nbuf)]
     stream = torch.cuda.current_stream().cuda_stream
+    pending = [[], []]
+    counter = [0]
 
     def step():
-        eng.resolve_dev(d_q.data_ptr(), Q, sub, d_rstat.data_ptr(), d_rscor.data_ptr(),
+        b = counter[0] % nbuf
+        counter[0] += 1
+        for w in pending[b]:           # the gather that last read this buffer set must be done
+            w.wait()
+        pending[b] = []
+        eng.resolve_dev(d_q.data_ptr(), Q, sub, d_rstats[b].data_ptr(), d_rscors[b].data_ptr(),
                         d_flags.data_ptr(), stream)
         if world > 1:
             # result gather: every rank ends up with the whole node's rows in global order
-            dist.all_gather_into_tensor(g_rstat, d_rstat.to(gdev))
-            dist.all_gather_into_tensor(g_rscor, d_rscor.to(gdev))
+            pending[b] = [
+                dist.all_gather_into_tensor(g_rstats[b], d_rstats[b].to(gdev), async_op=True),
+                dist.all_gather_into_tensor(g_rscors[b], d_rscors[b].to(gdev), async_op=True),
+            ]
 
     def fence():
+        for ws in pending:
+            for w in ws:
+                w.wait()
+            ws.clear()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -188,8 +204,9 @@ def main():
     eng.resolve(quartets, sub)
     pcie_inclusive = Q / (time.perf_counter() - t1)
 
-    rstat = d_rstat.cpu().numpy().astype(np.uint32)
-    rscor = d_rscor.cpu().numpy()
+    last = (counter[0] - 1) % nbuf
+    rstat = d_rstats[last].cpu().numpy().astype(np.uint32)
+    rscor = d_rscors[last].cpu().numpy()
     flags = d_flags.cpu().numpy()
 
     if rank == 0:

@@ -239,3 +239,19 @@ def test_full_size_properties_c3(engine):
     full = engine.resolve(q, False)[0][:, 1]
     sub_ = engine.resolve(q, True)[0][:, 1]
     assert (sub_ <= full).all()
+
+
+def test_c3_sample_vs_oracle(engine, oracle):
+    """2,500 random quartets of the c3 benchmark input, both modes, against the oracle: exact
+    counts / topology, scores within tolerance, no flagged rows."""
+    from tetrad_amd import synth
+    tmparr, tmpmap = synth.simulate_tmparr(128, 50_000, synth.CONFIG_SEEDS["c3"])
+    q = synth.random_quartets(128, 2500, seed=4321)
+    engine.set_data(tmparr, tmpmap)
+    for sub in (True, False):
+        rstat, rscor, flags = engine.resolve(q, sub)
+        _, o_rstat, o_rscor, o = oracle.new_infer_resolved_quartets(tmparr, tmpmap, q, sub, debug=True)
+        assert (flags == 0).all() and (o["flags"] == 0).all()
+        np.testing.assert_array_equal(rstat, o_rstat)
+        smax = o["svds"].max(axis=(1, 2))[:, None]
+        assert_close(rscor, o_rscor, smax, "scores")

@@ -231,7 +231,7 @@ __device__ __forceinline__ void hist_dword(uint32_t a, uint32_t b, uint32_t c, u
                                            uint32_t *hrep)
 {
     // base codes are 0..3, so the per-byte pattern (a<<6|b<<4|c<<2|d) never crosses a byte
-    const uint32_t pat = (((((a << 2) | b) << 2) | c) << 2) | d;
+    const uint32_t pat = (((((a << 2) + b) << 2) + c) << 2) + d;     // fields never overlap: + == |, one v_lshl_add each
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         if (C & (1u << (site0 + k)))
@@ -252,7 +252,7 @@ __device__ __forceinline__ void process_tile(const TileRegs &t, int lane, uint32
 {
     const uint32_t C = count_mask<SUB>(t, lane, tile_carry);
     if (METHOD == 2) {          // timing diagnostic: everything but the histogram (results are wrong)
-#define TQ_PAT(a, b, c, d) ((((((a) << 2) | (b)) << 2) | (c)) << 2 | (d))
+#define TQ_PAT(a, b, c, d) (((((((a) << 2) + (b)) << 2) + (c)) << 2) + (d))
         uint32_t acc = C;
         acc ^= TQ_PAT(t.a0.x, t.b0.x, t.c0.x, t.d0.x) ^ TQ_PAT(t.a0.y, t.b0.y, t.c0.y, t.d0.y);
         acc ^= TQ_PAT(t.a0.z, t.b0.z, t.c0.z, t.d0.z) ^ TQ_PAT(t.a0.w, t.b0.w, t.c0.w, t.d0.w);
@@ -271,7 +271,7 @@ __device__ __forceinline__ void process_tile(const TileRegs &t, int lane, uint32
         hist_dword<NREP>(t.a1.w, t.b1.w, t.c1.w, t.d1.w, C, 28, hrep);
     } else {
         uint32_t *pw = reinterpret_cast<uint32_t *>(park);
-#define TQ_PAT(a, b, c, d) ((((((a) << 2) | (b)) << 2) | (c)) << 2 | (d))
+#define TQ_PAT(a, b, c, d) (((((((a) << 2) + (b)) << 2) + (c)) << 2) + (d))
         pw[0] = TQ_PAT(t.a0.x, t.b0.x, t.c0.x, t.d0.x);
         pw[1] = TQ_PAT(t.a0.y, t.b0.y, t.c0.y, t.d0.y);
         pw[2] = TQ_PAT(t.a0.z, t.b0.z, t.c0.z, t.d0.z);
@@ -281,12 +281,30 @@ __device__ __forceinline__ void process_tile(const TileRegs &t, int lane, uint32
         pw[6] = TQ_PAT(t.a1.z, t.b1.z, t.c1.z, t.d1.z);
         pw[7] = TQ_PAT(t.a1.w, t.b1.w, t.c1.w, t.d1.w);
 #undef TQ_PAT
+        // set-bit walk, software pipelined: the pattern byte of the NEXT counted site is requested
+        // before the histogram increment of the current one, so the LDS read latency of one step
+        // hides behind the previous step instead of stalling every iteration
         uint32_t c = C;
-        while (c) {
-            const int i = __builtin_ctz(c);
+        if (c) {
+            // two alternating registers instead of a copy: a copy would wait for the read it copies
+            uint32_t b0 = park[__builtin_ctz(c)], b1 = 0;
             c &= c - 1;
-            const uint32_t bin = park[i];
-            __hip_atomic_fetch_add(&hrep[bin * NREP], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            for (;;) {
+                if (!c) {
+                    __hip_atomic_fetch_add(&hrep[b0 * NREP], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    break;
+                }
+                b1 = park[__builtin_ctz(c)];
+                c &= c - 1;
+                __hip_atomic_fetch_add(&hrep[b0 * NREP], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (!c) {
+                    __hip_atomic_fetch_add(&hrep[b1 * NREP], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    break;
+                }
+                b0 = park[__builtin_ctz(c)];
+                c &= c - 1;
+                __hip_atomic_fetch_add(&hrep[b1 * NREP], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
         }
     }
 }
@@ -381,29 +399,32 @@ struct OwnRegs {
     uint4 c0, c1, d0, d1, pc, pd;
 };
 
-__device__ __forceinline__ void load_own(OwnRegs &r, const DevData &d, uint32_t qc, uint32_t qd, int tile, int lane)
+// 16-byte load at a wave-uniform base + 32-bit per-lane byte offset (lets the compiler use the
+// SGPR-base addressing form instead of 64-bit VGPR pointer arithmetic for every load; the host
+// guarantees T*Sp < 2^32 before it selects this kernel)
+__device__ __forceinline__ uint4 ld16(const uint8_t *base, uint32_t off)
 {
-    const int64_t boff = (int64_t)tile * TILE + lane * 16;
-    const uint4 *pc = reinterpret_cast<const uint4 *>(d.rows + (int64_t)qc * d.pitch + boff);
-    const uint4 *pd = reinterpret_cast<const uint4 *>(d.rows + (int64_t)qd * d.pitch + boff);
-    r.c0 = pc[0]; r.c1 = pc[64];
-    r.d0 = pd[0]; r.d1 = pd[64];
-    const int64_t woff = (int64_t)tile * WAVE + lane;
-    r.pc = d.planes[(int64_t)qc * d.W + woff];
-    r.pd = d.planes[(int64_t)qd * d.W + woff];
+    return *reinterpret_cast<const uint4 *>(base + off);
+}
+
+// per-lane byte offsets of a wave's own rows c, d (rows array) and their plane records
+struct OwnOff {
+    uint32_t c, d, pc, pd;
+};
+
+__device__ __forceinline__ void load_own(OwnRegs &r, const uint8_t *rows, const uint8_t *planes, const OwnOff &o,
+                                         int tile)
+{
+    const uint32_t tb = (uint32_t)tile * TILE, tp = (uint32_t)tile * (WAVE * 16);
+    r.c0 = ld16(rows, o.c + tb);
+    r.c1 = ld16(rows, o.c + tb + 1024);
+    r.d0 = ld16(rows, o.d + tb);
+    r.d1 = ld16(rows, o.d + tb + 1024);
+    r.pc = ld16(planes, o.pc + tp);
+    r.pd = ld16(planes, o.pd + tp);
 }
 
 constexpr int SHARED_PIECES = 384;   // uint4 per step: row a 128, row b 128, planes a 64, planes b 64
-
-__device__ __forceinline__ uint4 load_shared_piece(const DevData &d, uint32_t la, uint32_t lb, int tile, int p)
-{
-    const uint4 *src;
-    if (p < 128) src = reinterpret_cast<const uint4 *>(d.rows + (int64_t)la * d.pitch + (int64_t)tile * TILE) + p;
-    else if (p < 256) src = reinterpret_cast<const uint4 *>(d.rows + (int64_t)lb * d.pitch + (int64_t)tile * TILE) + (p - 128);
-    else if (p < 320) src = d.planes + (int64_t)la * d.W + (int64_t)tile * WAVE + (p - 256);
-    else src = d.planes + (int64_t)lb * d.W + (int64_t)tile * WAVE + (p - 320);
-    return *src;
-}
 
 template <bool SUB, int METHOD, int NW>
 __global__ void __launch_bounds__(NW *WAVE)
@@ -423,6 +444,14 @@ tq_scan_wg_kernel(DevData d, const uint32_t *__restrict__ quartets, const uint32
     const uint32_t T = (uint32_t)d.T;
     const int last = d.ntiles - 1;
     const int64_t nblk = (Q + NW - 1) / NW;
+    const uint8_t *rows = d.rows;
+    const uint8_t *planes = reinterpret_cast<const uint8_t *>(d.planes);
+    const uint32_t pitch = (uint32_t)d.pitch, wpitch = (uint32_t)d.W * 16u;
+    // this thread's cooperative piece: waves 0-3 fetch row bytes of a / b, waves 4-5 plane records
+    const uint8_t *sh_base = tid < 256 ? rows : planes;                       // wave-uniform
+    const uint32_t sh_step = tid < 256 ? (uint32_t)TILE : (uint32_t)(WAVE * 16);
+    const uint32_t sh_lane = tid < 256 ? (uint32_t)(tid & 127) * 16u : (uint32_t)((tid - 256) & 63) * 16u;
+    const bool sh_is_b = tid < 256 ? (tid >= 128) : (tid >= 320);
     __syncthreads();
 
     for (int64_t blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
@@ -447,12 +476,18 @@ tq_scan_wg_kernel(DevData d, const uint32_t *__restrict__ quartets, const uint32
         const bool work = have && !bad;                     // wave-uniform
         const bool shares = work && leader_ok && q[0] == la && q[1] == lb;
         const uint32_t qc = work ? q[2] : 0, qd = work ? q[3] : 0;
+        OwnOff oo;
+        oo.c = qc * pitch + (uint32_t)lane * 16u;
+        oo.d = qd * pitch + (uint32_t)lane * 16u;
+        oo.pc = qc * wpitch + (uint32_t)lane * 16u;
+        oo.pd = qd * wpitch + (uint32_t)lane * 16u;
+        const uint32_t sh_off = (sh_is_b ? lb : la) * (tid < 256 ? pitch : wpitch) + sh_lane;
 
         // prologue: step 0 into buffer 0
         const int slot = tid;     // rows are stored in panels already (row_offset), so piece p is slot p
-        if (tid < SHARED_PIECES) shared_ab[0][slot] = load_shared_piece(d, la, lb, 0, tid);
+        if (tid < SHARED_PIECES) shared_ab[0][slot] = ld16(sh_base, sh_off);
         OwnRegs A, B;
-        load_own(A, d, qc, qd, 0, lane);
+        load_own(A, rows, planes, oo, 0);
         uint32_t tile_carry = 0;
         __syncthreads();
 
@@ -489,8 +524,8 @@ tq_scan_wg_kernel(DevData d, const uint32_t *__restrict__ quartets, const uint32
             {
                 const int tn = min(t + 1, last);
                 uint4 sh = make_uint4(0, 0, 0, 0);
-                if (tid < SHARED_PIECES) sh = load_shared_piece(d, la, lb, tn, tid);
-                load_own(B, d, qc, qd, tn, lane);
+                if (tid < SHARED_PIECES) sh = ld16(sh_base, sh_off + (uint32_t)tn * sh_step);
+                load_own(B, rows, planes, oo, tn);
                 __builtin_amdgcn_sched_barrier(0);
                 step(A, t);
                 __builtin_amdgcn_sched_barrier(0);
@@ -502,8 +537,8 @@ tq_scan_wg_kernel(DevData d, const uint32_t *__restrict__ quartets, const uint32
             {
                 const int tn = min(t + 2, last);
                 uint4 sh = make_uint4(0, 0, 0, 0);
-                if (tid < SHARED_PIECES) sh = load_shared_piece(d, la, lb, tn, tid);
-                load_own(A, d, qc, qd, tn, lane);
+                if (tid < SHARED_PIECES) sh = ld16(sh_base, sh_off + (uint32_t)tn * sh_step);
+                load_own(A, rows, planes, oo, tn);
                 __builtin_amdgcn_sched_barrier(0);
                 step(B, t + 1);
                 __builtin_amdgcn_sched_barrier(0);
@@ -1579,7 +1614,7 @@ int launch_scan_wg(tq_ctx *ctx, const uint32_t *dq, const uint32_t *order, int64
 int launch_scan_n(tq_ctx *ctx, const uint32_t *dq, const uint32_t *order, int64_t Q, int subsample,
                   hipStream_t stream)
 {
-    if (ctx->scan_wg == 8 && Q >= 64) {
+    if (ctx->scan_wg == 8 && Q >= 64 && (uint64_t)ctx->T * (uint64_t)ctx->Sp < 0xFFFF0000ull) {
         const int m = ctx->scan_method < 0 ? (subsample ? 1 : 0) : ctx->scan_method;
         if (m == 2) return launch_scan_wg<true, 2, 8>(ctx, dq, order, Q, stream);   // diagnostic
         if (subsample)

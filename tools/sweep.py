@@ -28,7 +28,7 @@ def main():
     ap.add_argument("--orders", default="1")
     ap.add_argument("--svds", default="1", help="svd_method list: 0 Jacobi, 1 HQR")
     ap.add_argument("--wgs", default="8", help="scan_wg list: 0 one wave per quartet, 8 cooperative")
-    ap.add_argument("--sort", default="none", choices=["none", "ab", "lex"], help="order of the quartet list")
+    ap.add_argument("--sort", default="none", choices=["none", "ab", "lex", "same"], help="order of the quartet list")
     args = ap.parse_args()
     import torch
     from tetrad_amd import synth
@@ -40,6 +40,8 @@ def main():
     quartets = synth.random_quartets(T, Q, 4242)
     if args.sort == "ab":
         quartets = quartets[np.argsort(quartets[:, 0].astype(np.int64) * T + quartets[:, 1], kind="stable")]
+    elif args.sort == "same":      # diagnostic: every quartet reads the same four rows (cache-hot)
+        quartets = np.tile(np.array([[3, 17, 40, 99]], np.uint32), (Q, 1))
     elif args.sort == "lex":
         quartets = quartets[np.lexsort((quartets[:, 3], quartets[:, 2], quartets[:, 1], quartets[:, 0]))]
     dev = torch.device("cuda:0")

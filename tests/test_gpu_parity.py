@@ -255,3 +255,26 @@ def test_c3_sample_vs_oracle(engine, oracle):
         np.testing.assert_array_equal(rstat, o_rstat)
         smax = o["svds"].max(axis=(1, 2))[:, None]
         assert_close(rscor, o_rscor, smax, "scores")
+
+
+def test_pipeline_options_do_not_change_results(engine):
+    """Two-stream overlapped pipeline, per-wave scan kernel, natural order, small batches: all must
+    give bitwise the same rows as the default configuration."""
+    g = load_golden("c1_T16_S5000")
+    engine.set_data(g["tmparr"], g["tmpmap"])
+    q = np.tile(g["quartets"], (3, 1))
+    base = engine.resolve(q, True)
+    try:
+        for opts in ({"overlap": 1024}, {"scan_wg": 0}, {"order": 0}, {"batch": 700}, {"scan_method": 0},
+                     {"overlap": 512, "ov_scan_wgs": 2, "ov_svd_waves": 4}):
+            for k, v in opts.items():
+                engine.set_option(k, v)
+            got = engine.resolve(q, True)
+            for a, b in zip(base, got):
+                np.testing.assert_array_equal(a, b)
+            for k in opts:
+                engine.set_option(k, {"scan_wg": 8, "order": 1, "scan_method": -1, "ov_scan_wgs": 1,
+                                      "ov_svd_waves": 6}.get(k, 0))
+    finally:
+        for k, v in (("overlap", 0), ("scan_wg", 8), ("order", 1), ("batch", 0), ("scan_method", -1)):
+            engine.set_option(k, v)

@@ -1429,6 +1429,14 @@ struct tq_ctx {
     uint32_t *d_nsnps = nullptr;
     int svd_method = 1;             // 0 = one-sided Jacobi (tq_svd_kernel), 1 = Householder + bidiagonal QR
     int scan_wg = 8;                // waves per workgroup of the cooperative scan kernel (0 = one wave per quartet)
+    // software pipeline across sub-batches: scan of sub-batch i+1 runs on a second stream beside the
+    // singular-value stage of sub-batch i (0 = off: one stage after the other on the caller's stream)
+    int64_t overlap = 0;            // sub-batch size in quartets
+    int ov_scan_wgs = 1;            // scan workgroups per CU while overlapping
+    int ov_svd_waves = 6;           // singular-value-stage waves per CU while overlapping
+    hipStream_t sA = nullptr, sB = nullptr;
+    hipEvent_t evIn = nullptr, evA[2] = {nullptr, nullptr}, evB[2] = {nullptr, nullptr}, evEndA = nullptr, evEndB = nullptr;
+    int wpc_override = 0;           // transient: grid_for() uses this instead of waves_per_cu when > 0
     // options
     int nrep = 1;
     int waves_per_cu = 0;           // 0 = from the occupancy query
@@ -1518,7 +1526,7 @@ int ensure_cm(tq_ctx *ctx, int64_t quartets)
     ctx->d_de = ctx->d_sv = nullptr;
     ctx->d_nsnps = nullptr;
     ctx->cm_quartets = 0;
-    TQ_HIP(ctx, hipMalloc((void **)&ctx->d_cm, (size_t)quartets * 1024));
+    TQ_HIP(ctx, hipMalloc((void **)&ctx->d_cm, (size_t)quartets * 1024 * 2));   // two slabs (overlap mode)
     TQ_HIP(ctx, hipMalloc((void **)&ctx->d_de, (size_t)quartets * 3 * 32 * sizeof(double)));
     TQ_HIP(ctx, hipMalloc((void **)&ctx->d_sv, (size_t)quartets * 3 * 16 * sizeof(double)));
     TQ_HIP(ctx, hipMalloc((void **)&ctx->d_nsnps, (size_t)quartets * sizeof(uint32_t)));
@@ -1566,7 +1574,7 @@ DevData dev_data(const tq_ctx *ctx)
 template <typename K>
 int grid_for(tq_ctx *ctx, K kern, int64_t items, int64_t *grid)
 {
-    int wpc = ctx->waves_per_cu;
+    int wpc = ctx->wpc_override > 0 ? ctx->wpc_override : ctx->waves_per_cu;
     if (wpc <= 0) {
         int nb = 0;
         TQ_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, WAVE, 0));
@@ -1595,7 +1603,8 @@ template <bool SUB, int METHOD, int NW>
 int launch_scan_wg(tq_ctx *ctx, const uint32_t *dq, const uint32_t *order, int64_t Q, hipStream_t stream)
 {
     auto kern = tq_scan_wg_kernel<SUB, METHOD, NW>;
-    int wgs = ctx->waves_per_cu > 0 ? (ctx->waves_per_cu + NW - 1) / NW : 0;
+    int wgs = ctx->wpc_override > 0 ? (ctx->wpc_override + NW - 1) / NW
+              : ctx->waves_per_cu > 0 ? (ctx->waves_per_cu + NW - 1) / NW : 0;
     if (wgs <= 0) {
         int nb = 0;
         TQ_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, NW * WAVE, 0));
@@ -1690,6 +1699,9 @@ OutPtrs offset_out(const OutPtrs &o, int64_t q0)
     return r;
 }
 
+int launch_overlapped(tq_ctx *ctx, const uint32_t *dq, int64_t Q, int subsample, const OutPtrs &out,
+                      hipStream_t stream);
+
 // scan kernel -> cm slab -> SVD kernel, in batches so that the slab stays <= batch KiB
 int launch(tq_ctx *ctx, const uint32_t *dq, int64_t Q, int subsample, bool debug, const OutPtrs &out,
            hipStream_t stream)
@@ -1699,6 +1711,8 @@ int launch(tq_ctx *ctx, const uint32_t *dq, int64_t Q, int subsample, bool debug
         return fail(ctx, TQ_ERR_LOCUS_ORDER,
                     "subsample mode needs each locus id in one contiguous run of sites (and no id 0xFFFFFFFF)");
     if (Q == 0) return TQ_OK;
+    if (ctx->overlap > 0 && !debug && ctx->phases == 3 && Q > ctx->overlap)
+        return launch_overlapped(ctx, dq, Q, subsample, out, stream);
     const int64_t batch = Q < ctx->batch ? Q : ctx->batch;
     int rc = ensure_cm(ctx, batch);
     if (rc) return rc;
@@ -1737,6 +1751,81 @@ int launch(tq_ctx *ctx, const uint32_t *dq, int64_t Q, int subsample, bool debug
         }
         if (ctx->timing) TQ_HIP(ctx, hipEventRecord(ev.e2, stream));
     }
+    return TQ_OK;
+}
+
+// Overlapped form of launch(): the batch is cut into sub-batches; scan(i+1) runs on stream A beside
+// the singular-value stage of sub-batch i on stream B (two count slabs).  Both grids are sized to a
+// fraction of each CU so that the two stages are co-resident: the scan is an L2/LDS/integer mix at
+// ~50 % VALU, the bidiagonal QR a latency-bound f64 chain at ~40 % -- they fill each other's gaps.
+int launch_overlapped(tq_ctx *ctx, const uint32_t *dq, int64_t Q, int subsample, const OutPtrs &out,
+                      hipStream_t stream)
+{
+    const int64_t sub = ctx->overlap;
+    int rc = ensure_cm(ctx, sub);
+    if (rc) return rc;
+    if (!ctx->sA) {
+        TQ_HIP(ctx, hipStreamCreateWithFlags(&ctx->sA, hipStreamNonBlocking));
+        TQ_HIP(ctx, hipStreamCreateWithFlags(&ctx->sB, hipStreamNonBlocking));
+        TQ_HIP(ctx, hipEventCreateWithFlags(&ctx->evIn, hipEventDisableTiming));
+        TQ_HIP(ctx, hipEventCreateWithFlags(&ctx->evEndA, hipEventDisableTiming));
+        TQ_HIP(ctx, hipEventCreateWithFlags(&ctx->evEndB, hipEventDisableTiming));
+        for (int i = 0; i < 2; ++i) {
+            TQ_HIP(ctx, hipEventCreateWithFlags(&ctx->evA[i], hipEventDisableTiming));
+            TQ_HIP(ctx, hipEventCreateWithFlags(&ctx->evB[i], hipEventDisableTiming));
+        }
+    }
+    tq_ctx::Ev ev{};
+    if (ctx->timing) {
+        ctx->timed_calls++;
+        if (ctx->events_used == ctx->events.size()) {
+            tq_ctx::Ev e{};
+            TQ_HIP(ctx, hipEventCreate(&e.e0));
+            TQ_HIP(ctx, hipEventCreate(&e.e1));
+            TQ_HIP(ctx, hipEventCreate(&e.e2));
+            ctx->events.push_back(e);
+        }
+        ev = ctx->events[ctx->events_used++];
+        TQ_HIP(ctx, hipEventRecord(ev.e0, stream));
+        TQ_HIP(ctx, hipEventRecord(ev.e1, stream));       // stages overlap: only the total is meaningful
+    }
+    TQ_HIP(ctx, hipEventRecord(ctx->evIn, stream));
+    TQ_HIP(ctx, hipStreamWaitEvent(ctx->sA, ctx->evIn, 0));
+    TQ_HIP(ctx, hipStreamWaitEvent(ctx->sB, ctx->evIn, 0));
+    uint32_t *cm0 = ctx->d_cm;
+    int64_t i = 0;
+    for (int64_t q0 = 0; q0 < Q; q0 += sub, ++i) {
+        const int64_t n = (Q - q0) < sub ? (Q - q0) : sub;
+        const int b = (int)(i & 1);
+        // stream A: ordering + scan into slab b (after the SVD stage that last read slab b)
+        if (i >= 2) TQ_HIP(ctx, hipStreamWaitEvent(ctx->sA, ctx->evB[b], 0));
+        ctx->d_cm = cm0 + (size_t)b * (size_t)ctx->cm_quartets * 256;
+        const uint32_t *order = nullptr;
+        rc = make_order(ctx, dq + q0 * 4, n, ctx->sA, &order);
+        if (!rc) {
+            ctx->wpc_override = ctx->ov_scan_wgs * 8;
+            rc = launch_scan_n(ctx, dq + q0 * 4, order, n, subsample, ctx->sA);
+        }
+        if (!rc && hipEventRecord(ctx->evA[b], ctx->sA) != hipSuccess) rc = TQ_ERR_HIP;
+        // stream B: singular values of slab b
+        if (!rc && hipStreamWaitEvent(ctx->sB, ctx->evA[b], 0) != hipSuccess) rc = TQ_ERR_HIP;
+        if (!rc) {
+            ctx->wpc_override = ctx->ov_svd_waves;
+            const OutPtrs o = offset_out(out, q0);
+            rc = ctx->svd_method == 0 ? launch_svd<false>(ctx, dq + q0 * 4, n, o, ctx->sB)
+                                      : launch_hqr<false>(ctx, dq + q0 * 4, n, o, ctx->sB);
+        }
+        if (!rc && hipEventRecord(ctx->evB[b], ctx->sB) != hipSuccess) rc = TQ_ERR_HIP;
+        if (rc) break;
+    }
+    ctx->wpc_override = 0;
+    ctx->d_cm = cm0;
+    if (rc) return rc > 0 ? TQ_ERR_HIP : rc;
+    TQ_HIP(ctx, hipEventRecord(ctx->evEndA, ctx->sA));
+    TQ_HIP(ctx, hipEventRecord(ctx->evEndB, ctx->sB));
+    TQ_HIP(ctx, hipStreamWaitEvent(stream, ctx->evEndA, 0));
+    TQ_HIP(ctx, hipStreamWaitEvent(stream, ctx->evEndB, 0));
+    if (ctx->timing) TQ_HIP(ctx, hipEventRecord(ev.e2, stream));
     return TQ_OK;
 }
 
@@ -1783,6 +1872,17 @@ void tq_destroy(tq_ctx *ctx)
     if (ctx->d_de) (void)hipFree(ctx->d_de);
     if (ctx->d_sv) (void)hipFree(ctx->d_sv);
     if (ctx->d_nsnps) (void)hipFree(ctx->d_nsnps);
+    if (ctx->sA) {
+        (void)hipStreamDestroy(ctx->sA);
+        (void)hipStreamDestroy(ctx->sB);
+        (void)hipEventDestroy(ctx->evIn);
+        (void)hipEventDestroy(ctx->evEndA);
+        (void)hipEventDestroy(ctx->evEndB);
+        for (int i = 0; i < 2; ++i) {
+            (void)hipEventDestroy(ctx->evA[i]);
+            (void)hipEventDestroy(ctx->evB[i]);
+        }
+    }
     for (auto &e : ctx->events) {
         (void)hipEventDestroy(e.e0);
         (void)hipEventDestroy(e.e1);
@@ -1997,44 +2097,59 @@ int tq_set_option(tq_ctx *ctx, const char *name, int64_t value)
         if (value == 1 || value == 2 || value == 4 || value == 8 || value == 16 || value == 32) ctx->nrep = (int)value;
         else if (value != 0) return fail(ctx, TQ_ERR_INVALID_ARG, "nrep must be 1,2,4,8,16 or 32");
         else ctx->nrep = 1;
-        return ctx->nrep;
+        return TQ_OK;
     }
     if (!strcmp(name, "waves_per_cu")) {
         if (value < 0 || value > 32) return fail(ctx, TQ_ERR_INVALID_ARG, "waves_per_cu must be 0..32");
         ctx->waves_per_cu = (int)value;
-        return ctx->waves_per_cu;
+        return TQ_OK;
+    }
+    if (!strcmp(name, "overlap")) {
+        if (value < 0) return fail(ctx, TQ_ERR_INVALID_ARG, "overlap must be >= 0");
+        ctx->overlap = value;
+        return TQ_OK;
+    }
+    if (!strcmp(name, "ov_scan_wgs")) {
+        if (value < 1 || value > 4) return fail(ctx, TQ_ERR_INVALID_ARG, "ov_scan_wgs must be 1..4");
+        ctx->ov_scan_wgs = (int)value;
+        return TQ_OK;
+    }
+    if (!strcmp(name, "ov_svd_waves")) {
+        if (value < 1 || value > 32) return fail(ctx, TQ_ERR_INVALID_ARG, "ov_svd_waves must be 1..32");
+        ctx->ov_svd_waves = (int)value;
+        return TQ_OK;
     }
     if (!strcmp(name, "scan_wg")) {
         if (value != 0 && value != 8) return fail(ctx, TQ_ERR_INVALID_ARG, "scan_wg must be 0 or 8");
         ctx->scan_wg = (int)value;
-        return ctx->scan_wg;
+        return TQ_OK;
     }
     if (!strcmp(name, "svd_method")) {
         if (value != 0 && value != 1) return fail(ctx, TQ_ERR_INVALID_ARG, "svd_method must be 0 (Jacobi) or 1 (HQR)");
         ctx->svd_method = (int)value;
-        return ctx->svd_method;
+        return TQ_OK;
     }
     if (!strcmp(name, "order")) {
         if (value != 0 && value != 1) return fail(ctx, TQ_ERR_INVALID_ARG, "order must be 0 or 1");
         ctx->order = (int)value;
-        return ctx->order;
+        return TQ_OK;
     }
     if (!strcmp(name, "scan_method")) {
         if (value != 0 && value != 1 && value != -1 && value != 2)
             return fail(ctx, TQ_ERR_INVALID_ARG, "scan_method must be -1 (auto), 0, 1 (or 2: timing diagnostic)");
         ctx->scan_method = (int)value;
-        return ctx->scan_method;
+        return TQ_OK;
     }
     if (!strcmp(name, "batch")) {
         if (value < 0) return fail(ctx, TQ_ERR_INVALID_ARG, "batch must be >= 0");
         ctx->batch = value ? value : (1 << 20);
-        return (int)(ctx->batch > 0x7FFFFFFF ? 0x7FFFFFFF : ctx->batch);
+        return TQ_OK;
     }
     if (!strcmp(name, "phases")) {
         if (value != 0 && value != 1 && value != 2 && value != 3)
             return fail(ctx, TQ_ERR_INVALID_ARG, "phases must be 1, 2 or 3");
         ctx->phases = value ? (int)value : 3;
-        return ctx->phases;
+        return TQ_OK;
     }
     return fail(ctx, TQ_ERR_INVALID_ARG, "unknown option '%s'", name);
 }

@@ -102,10 +102,8 @@ class QuartetEngine:
         return tmparr, tmpmap
 
     def set_option(self, name: str, value: int) -> int:
-        rc = self._lib.tq_set_option(self._h, name.encode(), int(value))
-        if rc < 0:
-            self._check(rc)
-        return rc
+        self._check(self._lib.tq_set_option(self._h, name.encode(), int(value)))
+        return int(value)
 
     # -- host-buffer API -----------------------------------------------------
     def resolve(self, quartets: np.ndarray, subsample_snps: bool = True, debug: bool = False):

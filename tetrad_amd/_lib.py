@@ -42,7 +42,8 @@ class TetradHipError(RuntimeError):
 def build(force: bool = False, verbose: bool = False) -> Path:
     """Compile the HIP library in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-    newest_src = max(SRC_PATH.stat().st_mtime, HEADER.stat().st_mtime)
+    sources = [SRC_PATH, HEADER, *CSRC.glob("*.hpp")]
+    newest_src = max(p.stat().st_mtime for p in sources)
     if not force and LIB_PATH.exists() and LIB_PATH.stat().st_mtime >= newest_src:
         return LIB_PATH
     cmd = [hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared",

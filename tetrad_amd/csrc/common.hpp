@@ -1,0 +1,42 @@
+// common.hpp -- constants, device-side views of the resident data, output pointer bundle
+// Part of the single translation unit tetrad_hip.hip (included inside its anonymous namespace).
+#pragma once
+
+
+constexpr int WAVE = 64;
+constexpr int SITES_PER_LANE = 32;
+constexpr int TILE = WAVE * SITES_PER_LANE;        // 2048 sites per wave step
+constexpr int QPW = 4;                              // quartets per wave pass of the SVD kernel
+constexpr double F64_EPS = 2.220446049250313e-16;
+constexpr double JTOL2 = 7.888609052210118e-31;     // (2^-50)^2 : rotate while g^2 > JTOL2*a*b
+constexpr double JEARLY2 = 1e-10;                   // (1e-5)^2 : see jacobi16
+constexpr int MAX_SWEEPS = 30;
+constexpr double DEGENERATE_REL_GAP = 1e-9;
+
+struct DevData {
+    const uint8_t *rows;
+    const uint4 *planes;
+    int64_t pitch;      // bytes per row (Sp)
+    int64_t W;          // plane records per row (Sp/32)
+    int32_t T;
+    int32_t ntiles;     // Sp / TILE
+};
+
+// Byte offset of site s inside a row.  A 2048-site step is stored as two 1 KiB panels: panel 0
+// holds sites 0-15 of every lane's 32-site group, panel 1 holds sites 16-31, so each of the two
+// 16-byte loads a lane issues per row is part of one fully contiguous 1 KiB wave access.
+__host__ __device__ __forceinline__ int64_t row_offset(int64_t s)
+{
+    const int64_t tile = s >> 11, r = s & 2047, lane = r >> 5, k = r & 31;
+    return (tile << 11) + ((k >> 4) << 10) + (lane << 4) + (k & 15);
+}
+
+struct OutPtrs {
+    uint32_t *rstat;    // [Q,2]
+    double *rscor;      // [Q,3]
+    uint8_t *flags;     // [Q] or null
+    uint32_t *cmats;    // [Q,3,16,16] or null (debug)
+    double *svds;       // [Q,3,16] or null (debug)
+    int32_t *ranks;     // [Q,3] or null (debug)
+};
+

@@ -1,0 +1,391 @@
+// hqr.hpp -- Householder bidiagonalisation + bidiagonal QR + score kernel (default singular-value path)
+// Part of the single translation unit tetrad_hip.hip (included inside its anonymous namespace).
+#pragma once
+
+// ====================================================================================
+// Default singular-value path ("HQR"): Householder bidiagonalisation + implicit-shift QR
+// on the bidiagonal -- the same algorithm class as the LAPACK routine the reference calls
+// (resolve_quartets.py:242 -> dgesdd -> dgebrd + bidiagonal QR), ~8x fewer f64 operations
+// than Jacobi.  Three kernels:
+//   tq_bidiag_kernel : 4 lanes per matrix (lane c of a quad holds columns c, c+4, c+8, c+12 as
+//                      64 f64 registers), 16 quartets per wave pass; Householder vectors are
+//                      shared inside the quad with DPP quad_perm broadcasts, row sums with two
+//                      quad_perm butterflies -- no LDS traffic after the count slabs are staged.
+//   tq_bdsqr_kernel  : 1 lane per matrix, diagonal/superdiagonal parked in LDS (lane-major, so
+//                      dynamically indexed accesses are bank-conflict free); Golub-Kahan
+//                      implicit-shift QR sweeps with deflation.
+//   tq_score_kernel  : 1 lane per quartet: sort, rank rule, minrank, tail norms, argmin, flags.
+// The Jacobi kernel (jacobi.hpp) stays selectable (tq_set_option "svd_method" 0) and is the
+// cross-check for this path in the GPU tests.
+// ====================================================================================
+template <int K>
+struct IC {
+    static constexpr int value = K;
+};
+
+template <int B, int E, typename F>
+__device__ __forceinline__ void static_for(F &&f)
+{
+    if constexpr (B < E) {
+        f(IC<B>{});
+        static_for<B + 1, E>(f);
+    }
+}
+
+template <int SRC>
+__device__ __forceinline__ double quad_bcast(double v)
+{
+    constexpr int CTRL = SRC | (SRC << 2) | (SRC << 4) | (SRC << 6);
+    const int lo = dpp_mov<CTRL>(__double2loint(v));
+    const int hi = dpp_mov<CTRL>(__double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ double quad_sum(double v)
+{
+    v += dpx<1>(v);
+    v += dpx<2>(v);
+    return v;
+}
+
+__device__ __forceinline__ double sqrt_nr(double x)     // x >= 0, full precision, sqrt(0) = 0
+{
+    const double y = rsq_nr<2>(x);
+    const double s = x * y;
+    const double r = fma(fma(-s, s, x), 0.5 * y, s);     // one more correction on the root itself
+    return x > 0.0 ? r : 0.0;
+}
+
+// de layout: f64 [3*Q][32]: d[0..15] then e[0..15] with e[0] = 0 (e[i] couples columns i-1, i)
+template <bool DEBUG>
+__global__ void __launch_bounds__(WAVE, 2)
+tq_bidiag_kernel(const uint32_t *__restrict__ cm, int64_t Q, double *__restrict__ de,
+                 uint32_t *__restrict__ nsnps_out, uint32_t *__restrict__ cmats_dbg)
+{
+    constexpr int QP = 16;                       // quartets per wave pass (one per quad)
+    __shared__ uint32_t lds[QP * 256];
+    const int lane = threadIdx.x;
+    const int quad = lane >> 2;
+    const int c = lane & 3;
+
+    const int64_t npass = (Q + QP - 1) / QP;
+    for (int64_t wg = blockIdx.x; wg < npass; wg += gridDim.x) {
+        const int64_t q0 = wg * QP;
+        {
+            const uint4 *src = reinterpret_cast<const uint4 *>(cm + q0 * 256);
+            uint4 *dst = reinterpret_cast<uint4 *>(lds);
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const int idx = lane + WAVE * k;               // 1024 uint4 = 16 quartets x 64
+                const bool ok = (q0 + (idx >> 6)) < Q;
+                dst[idx] = ok ? src[idx] : make_uint4(0, 0, 0, 0);
+            }
+        }
+        __syncthreads();
+        const int64_t myq = q0 + quad;
+        const uint32_t *cmq = lds + 256 * quad;
+        // resolve_quartets.py:226: number of counted sites = sum of the count tensor
+        {
+            uint32_t s = 0;
+#pragma unroll
+            for (int k = 0; k < 64; ++k) s += cmq[4 * k + c];
+            s += __shfl_xor(s, 1, WAVE);
+            s += __shfl_xor(s, 2, WAVE);
+            if (c == 0 && myq < Q) nsnps_out[myq] = s;
+        }
+#pragma unroll 1
+        for (int t = 0; t < 3; ++t) {
+            double a[4][16];                                    // a[s][r] = M_t[r][4s + c]
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const uint32_t v = cmq[flat_bin(t, r, 4 * s + c)];
+                    a[s][r] = (double)v;
+                    if (DEBUG) {
+                        if (cmats_dbg && myq < Q) cmats_dbg[((myq * 3 + t) * 16 + r) * 16 + 4 * s + c] = v;
+                    }
+                }
+            }
+            // d[K] / e[K] are stored as soon as they are known (keeping 32 more f64 live would cost
+            // the kernel its second wave per SIMD)
+            double *dout = de + (myq * 3 + t) * 32;
+            const bool writer = (c == 0) && (myq < Q);
+            if (writer) dout[16] = 0.0;
+            static_for<0, 16>([&](auto kc) {
+                constexpr int K = decltype(kc)::value;
+                // ---- left reflector: zero column K below the diagonal ----
+                {
+                    constexpr int so = K >> 2, co = K & 3;
+                    double v[16];
+#pragma unroll
+                    for (int r = K; r < 16; ++r) v[r] = quad_bcast<co>(a[so][r]);
+                    double n2 = 0.0;
+#pragma unroll
+                    for (int r = K; r < 16; ++r) n2 = fma(v[r], v[r], n2);
+                    const double nrm = sqrt_nr(n2);
+                    const double x0 = v[K];
+                    const double alpha = (x0 < 0.0) ? nrm : -nrm;
+                    v[K] = x0 - alpha;
+                    const double den = fma(-alpha, x0, n2);      // = |v|^2 / 2 > 0 unless the column is zero
+                    const double beta = n2 > 0.0 ? rcp_nr<2>(den) : 0.0;
+                    if (writer) dout[K] = alpha;
+#pragma unroll
+                    for (int s = so; s < 4; ++s) {
+                        double w = 0.0;
+#pragma unroll
+                        for (int r = K; r < 16; ++r) w = fma(v[r], a[s][r], w);
+                        w *= beta;
+                        if (s == so) w = (c > co) ? w : 0.0;     // columns <= K of this slot are finished
+#pragma unroll
+                        for (int r = K; r < 16; ++r) a[s][r] = fma(-w, v[r], a[s][r]);
+                    }
+                }
+                // ---- right reflector: zero row K right of the superdiagonal ----
+                if constexpr (K <= 13) {
+                    constexpr int K1 = K + 1, s1 = K1 >> 2, c1 = K1 & 3, sb = K1 >> 2;
+                    double y[4];
+                    double p = 0.0;
+#pragma unroll
+                    for (int s = sb; s < 4; ++s) {
+                        y[s] = (4 * s + c > K) ? a[s][K] : 0.0;
+                        p = fma(y[s], y[s], p);
+                    }
+                    const double n2 = quad_sum(p);
+                    const double x0 = quad_bcast<c1>(y[s1]);
+                    const double nrm = sqrt_nr(n2);
+                    const double alpha = (x0 < 0.0) ? nrm : -nrm;
+                    const double den = fma(-alpha, x0, n2);
+                    const double beta = n2 > 0.0 ? rcp_nr<2>(den) : 0.0;
+                    if (c == c1) y[s1] = x0 - alpha;
+                    if (writer) dout[16 + K1] = alpha;
+#pragma unroll
+                    for (int i = K1; i < 16; ++i) {
+                        double q = 0.0;
+#pragma unroll
+                        for (int s = sb; s < 4; ++s) q = fma(y[s], a[s][i], q);
+                        const double tt = beta * quad_sum(q);
+#pragma unroll
+                        for (int s = sb; s < 4; ++s) a[s][i] = fma(-tt, y[s], a[s][i]);
+                    }
+                } else if constexpr (K == 14) {
+                    const double e15 = quad_bcast<3>(a[3][14]);  // column 15 lives in slot 3 of lane 3
+                    if (writer) dout[31] = e15;
+                }
+            });
+        }
+        __syncthreads();
+    }
+}
+
+// Golub-Kahan implicit-shift QR on one 16x16 bidiagonal per lane (Golub & Reinsch 1970, the
+// diagonalisation half of their SVD procedure, singular values only).  w = diagonal, e =
+// superdiagonal (e[0] unused), both parked lane-major in LDS.  sv out: f64 [nmat][16], unsorted, >= 0.
+#define W_(i) wl[(i) * WAVE]
+#define E_(i) el[(i) * WAVE]
+__device__ __forceinline__ double hypot_nr(double a, double b) { return sqrt_nr(fma(a, a, b * b)); }
+
+__global__ void __launch_bounds__(WAVE)
+tq_bdsqr_kernel(const double *__restrict__ de, int64_t nmat, double *__restrict__ sv)
+{
+    __shared__ double lds[32 * WAVE];
+    const int lane = threadIdx.x;
+    double *wl = lds + lane;
+    double *el = lds + 16 * WAVE + lane;
+    const int64_t npass = (nmat + WAVE - 1) / WAVE;
+    for (int64_t wg = blockIdx.x; wg < npass; wg += gridDim.x) {
+        const int64_t m = wg * WAVE + lane;
+        const bool live = m < nmat;
+        double anorm = 0.0;
+        double dv[16], ev[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            dv[i] = live ? de[m * 32 + i] : 0.0;
+            ev[i] = live ? de[m * 32 + 16 + i] : 0.0;
+            W_(i) = dv[i];
+            E_(i) = ev[i];
+            anorm = fmax(anorm, fabs(dv[i]) + fabs(ev[i]));
+        }
+        // negligible(x): |x| + anorm == anorm, i.e. |x| <= ~eps/2 * anorm
+        const double tiny = anorm * (0.5 * F64_EPS);
+        // bit i of negE / negW: e[i] / w[i] is negligible.  Kept in registers and updated on every
+        // store, so the split search is a few bit operations instead of a dependent chain of LDS reads.
+        uint32_t negE = 0, negW = 0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            negE |= (uint32_t)(fabs(ev[i]) <= tiny) << i;
+            negW |= (uint32_t)(fabs(dv[i]) <= tiny) << i;
+        }
+#define SET_E(i, v) do { const double v_ = (v); E_(i) = v_; negE = (negE & ~(1u << (i))) | ((uint32_t)(fabs(v_) <= tiny) << (i)); } while (0)
+#define SET_W(i, v) do { const double v_ = (v); W_(i) = v_; negW = (negW & ~(1u << (i))) | ((uint32_t)(fabs(v_) <= tiny) << (i)); } while (0)
+        // Every lane walks its own deflation index k: a lane whose current singular value has
+        // converged moves on at once instead of waiting for the slowest lane of the wave at that k.
+        int k = 15, its = 0;
+        while (k >= 0) {
+            // split point l = largest l <= k with e[l] negligible (or l == 0), unless a negligible
+            // w[l-1] is met first (then e[l] has to be chased out of the block: "cancel")
+            const uint32_t stopE = negE | 1u, stopW = negW << 1;
+            const uint32_t stops = (stopE | stopW) & ((2u << k) - 1u);
+            const int l = 31 - __builtin_clz(stops);
+            const bool cancel = ((stopE >> l) & 1u) == 0;
+            if (cancel) {
+                double cc = 0.0, ss = 1.0;
+                for (int i = l; i <= k; ++i) {
+                    const double ei = E_(i);
+                    const double f = ss * ei;
+                    SET_E(i, cc * ei);
+                    if (fabs(f) <= tiny) break;
+                    const double g = W_(i);
+                    const double h = hypot_nr(f, g);
+                    SET_W(i, h);
+                    const double hi = rcp_nr<2>(h);
+                    cc = g * hi;
+                    ss = -f * hi;
+                }
+            }
+            double z = W_(k);
+            if (l == k || its >= 60) {          // converged (or iteration cap: keep what we have)
+                W_(k) = fabs(z);
+                --k;
+                its = 0;
+                continue;
+            }
+            ++its;
+            // shift from the bottom 2x2 minor
+            double x = W_(l);
+            const int nm = k - 1;
+            double y = W_(nm);
+            double g = E_(nm);
+            double h = E_(k);
+            double f = ((y - z) * (y + z) + (g - h) * (g + h)) * rcp_nr<2>(2.0 * h * y);
+            g = hypot_nr(f, 1.0);
+            f = ((x - z) * (x + z) + h * (y * rcp_nr<2>(f + copysign(g, f)) - h)) * rcp_nr<2>(x);
+            double cc = 1.0, ss = 1.0;
+            // one QR sweep over the block [l,k]; the LDS reads of the next step are issued
+            // before the current step's arithmetic, and each hypot shares one rsq with the
+            // reciprocal its rotation needs
+            double gn = E_(l + 1), yn = W_(l + 1);
+            for (int jj = l; jj <= nm; ++jj) {
+                g = gn;
+                y = yn;
+                const int i2 = min(jj + 2, 15);
+                gn = E_(i2);
+                yn = W_(i2);
+                h = ss * g;
+                g = cc * g;
+                double zz = fma(f, f, h * h);
+                double rz = zz > 0.0 ? rsq_nr<2>(zz) : 0.0;
+                SET_E(jj, zz * rz);
+                cc = f * rz;
+                ss = h * rz;
+                f = fma(x, cc, g * ss);
+                g = fma(g, cc, -(x * ss));
+                h = y * ss;
+                y *= cc;
+                zz = fma(f, f, h * h);
+                rz = zz > 0.0 ? rsq_nr<2>(zz) : 0.0;
+                SET_W(jj, zz * rz);
+                if (zz > 0.0) {
+                    cc = f * rz;
+                    ss = h * rz;
+                }
+                f = fma(cc, g, ss * y);
+                x = fma(cc, y, -(ss * g));
+            }
+            SET_E(l, 0.0);
+            SET_E(k, f);
+            SET_W(k, x);
+        }
+#undef SET_E
+#undef SET_W
+        if (live) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) sv[m * 16 + i] = fabs(W_(i));
+        }
+    }
+}
+#undef W_
+#undef E_
+
+// one lane per quartet: resolve_quartets.py:243-251 on the three sets of singular values
+template <bool DEBUG>
+__global__ void __launch_bounds__(256)
+tq_score_kernel(const double *__restrict__ sv, const uint32_t *__restrict__ nsnps_in,
+                const uint32_t *__restrict__ quartets, int64_t Q, int32_t T, OutPtrs out)
+{
+    const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= Q) return;
+    double sc2[3][16];
+    int rnk[3];
+    double smax_all = 0.0;
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+        double s[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) s[i] = sv[(q * 3 + t) * 16 + i];
+        // bitonic sorting network, descending (static indices only)
+#pragma unroll
+        for (int k = 2; k <= 16; k <<= 1) {
+#pragma unroll
+            for (int jj = k >> 1; jj > 0; jj >>= 1) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int l = i ^ jj;
+                    if (l > i) {
+                        const bool desc = (i & k) == 0;
+                        const double lo = fmin(s[i], s[l]), hi = fmax(s[i], s[l]);
+                        s[i] = desc ? hi : lo;
+                        s[l] = desc ? lo : hi;
+                    }
+                }
+            }
+        }
+        const double thr = s[0] * 16.0 * F64_EPS;        // numpy.linalg.matrix_rank rule
+        int r = 0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            r += s[i] > thr;
+            sc2[t][i] = s[i] * s[i];
+            if (DEBUG) {
+                if (out.svds) out.svds[(q * 3 + t) * 16 + i] = s[i];
+            }
+        }
+        rnk[t] = r;
+        smax_all = fmax(smax_all, s[0]);
+        if (DEBUG) {
+            if (out.ranks) out.ranks[q * 3 + t] = r;
+        }
+    }
+    const int minrank = min(10, min(rnk[0], min(rnk[1], rnk[2])));
+    double sc[3];
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+        double acc = 0.0;
+#pragma unroll
+        for (int i = 15; i >= 0; --i) acc += (i >= minrank) ? sc2[t][i] : 0.0;
+        sc[t] = sqrt(acc);
+    }
+    int topo = 0;
+    if (sc[1] < sc[topo]) topo = 1;
+    if (sc[2] < sc[topo]) topo = 2;
+    const double lo1 = sc[topo];
+    const double lo2 = (topo == 0) ? fmin(sc[1], sc[2]) : (topo == 1) ? fmin(sc[0], sc[2]) : fmin(sc[0], sc[1]);
+    uint32_t fl = 0;
+    if ((lo2 - lo1) <= DEGENERATE_REL_GAP * smax_all) fl |= TQ_FLAG_DEGENERATE;
+    const uint32_t nsn = nsnps_in[q];
+    if (nsn == 0) {
+        topo = 0;
+        sc[0] = sc[1] = sc[2] = 0.001;
+        fl = TQ_FLAG_ZERO_DATA;
+    }
+    const uint4 qv = reinterpret_cast<const uint4 *>(quartets)[q];
+    const uint32_t Tu = (uint32_t)T;
+    if ((qv.x >= Tu) | (qv.y >= Tu) | (qv.z >= Tu) | (qv.w >= Tu)) fl |= TQ_FLAG_BAD_INDEX;
+    out.rstat[q * 2 + 0] = (uint32_t)topo;
+    out.rstat[q * 2 + 1] = nsn;
+    out.rscor[q * 3 + 0] = sc[0];
+    out.rscor[q * 3 + 1] = sc[1];
+    out.rscor[q * 3 + 2] = sc[2];
+    if (out.flags) out.flags[q] = (uint8_t)fl;
+}
+

@@ -1,0 +1,79 @@
+// prepare.hpp -- layout build, lexicographic unranking, sort keys
+// Part of the single translation unit tetrad_hip.hip (included inside its anonymous namespace).
+#pragma once
+
+// ------------------------------------------------------------------------------------
+// data preparation kernel: one thread per 32-site word of one taxon row
+// ------------------------------------------------------------------------------------
+__global__ void tq_prepare_rows(const uint8_t *__restrict__ raw, const uint32_t *__restrict__ locus,
+                                int64_t S, int64_t Sp, int64_t W, int32_t T, uint8_t *__restrict__ rows,
+                                uint4 *__restrict__ planes)
+{
+    int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= (int64_t)T * W) return;
+    int64_t t = gid / W, w = gid - t * W;
+    const uint8_t *src = raw + t * S + w * 32;
+    uint8_t *dst = rows + t * Sp;
+    uint32_t mm = 0, b0 = 0, b1 = 0, rb = 0;
+    for (int i = 0; i < 32; ++i) {
+        int64_t s = w * 32 + i;
+        uint8_t v = (s < S) ? src[i] : (uint8_t)0xFF;
+        bool missing = v > 3;
+        uint8_t code = missing ? (uint8_t)0 : v;
+        dst[row_offset(s)] = code;
+        mm |= (uint32_t)missing << i;
+        b0 |= (uint32_t)(code & 1) << i;
+        b1 |= (uint32_t)((code >> 1) & 1) << i;
+        if (s < S) {
+            bool beg = (s == 0) || (locus[s] != locus[s - 1]);
+            rb |= (uint32_t)beg << i;
+        }
+    }
+    planes[t * W + w] = make_uint4(mm, b0, b1, rb);
+}
+
+// ------------------------------------------------------------------------------------
+// lexicographic unranking of 4-combinations (combinations.py:94-106)
+// ------------------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t choose_k(uint64_t n, int k)
+{
+    switch (k) {
+    case 0: return 1;
+    case 1: return n;
+    case 2: return n < 2 ? 0 : n * (n - 1) / 2;
+    default: return n < 3 ? 0 : n * (n - 1) / 2 * (n - 2) / 3;
+    }
+}
+
+__global__ void tq_unrank_kernel(const uint64_t *__restrict__ ranks, uint64_t first_rank, int64_t Q,
+                                 int32_t T, uint32_t *__restrict__ quartets)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= Q) return;
+    uint64_t index = ranks ? ranks[i] : first_rank + (uint64_t)i;
+    uint32_t out[4] = {0, 0, 0, 0};
+    int nsel = 0;
+    for (int t = 0; t < T && nsel < 4; ++t) {
+        uint64_t c = choose_k((uint64_t)(T - t - 1), 4 - nsel - 1);
+        if (c > index) {
+            out[nsel++] = (uint32_t)t;
+        } else {
+            index -= c;
+        }
+    }
+    uint4 v = make_uint4(out[0], out[1], out[2], out[3]);
+    reinterpret_cast<uint4 *>(quartets)[i] = v;
+}
+
+// sort key of a quartet: its first two taxa (quartets sharing them share two of their four rows)
+__global__ void tq_key_kernel(const uint32_t *__restrict__ quartets, int64_t Q, uint32_t T,
+                              uint32_t *__restrict__ keys, uint32_t *__restrict__ idx)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= Q) return;
+    const uint4 q = reinterpret_cast<const uint4 *>(quartets)[i];
+    const uint32_t a = q.x < T ? q.x : T - 1, b = q.y < T ? q.y : T - 1;
+    keys[i] = a * T + b;
+    idx[i] = (uint32_t)i;
+}
+

@@ -14,23 +14,17 @@
 //                        (W = Sp/32; run-begin = site starts a new locus run, same for every row,
 //                        replicated so that one 16-byte load brings everything a lane needs)
 //
-// Kernel 1, tq_scan_kernel: one wavefront per quartet, persistent grid.  The wave scans 2048
-//   sites per step; lane l owns 32 consecutive sites: 2 x dwordx4 of each of the 4 rows
-//   (coalesced 2 KiB per row per step) + one 16-byte plane record per row, prefetched one step
-//   ahead.  Which sites count is pure bit logic on 32-site words: U = variable-among-the-4 &
-//   ~missing (resolve_quartets.py:216-218); in subsample mode additionally "first unmasked site
-//   of its locus run" (:58-64) via an adder carry chain, cross-lane carries resolved on the
-//   scalar unit from two ballots.  The 8-bit site pattern (a<<6|b<<4|c<<2|d) is built 4 sites
-//   per VALU op (SWAR) and counted with EXEC-masked ds_add_u32 into an LDS histogram with NREP
-//   lane-interleaved replicas; the folded 256 counts go to a scratch slab cm[Q][256] (1 KiB per
-//   quartet, L2/MALL resident between the two kernels).
-// Kernel 2, tq_svd_kernel: each 16-lane group takes one quartet; lane j holds column j (16 f64)
-//   of a flattening and the group runs a one-sided (Hestenes) Jacobi SVD with the XOR-partner
-//   parallel ordering (15 rounds per sweep, partner = lane ^ m, exchanged with DPP moves).  Rank
-//   rule, minrank, tail-norm scores and argmin follow resolve_quartets.py:241-251.
+// Kernels (each in its own header of this directory, all included below into one translation unit):
+//   prepare.hpp   layout build, lexicographic unranking, sort keys
+//   scan.hpp      tq_scan_wg_kernel / tq_scan_kernel: site scan -> 256 pattern counts per quartet
+//   hqr.hpp       tq_bidiag_kernel + tq_bdsqr_kernel + tq_score_kernel: singular values (default)
+//   jacobi.hpp    tq_svd_kernel: one-sided Jacobi singular values in registers (alternative)
+//   bootstrap.hpp tq_boot_*: bootstrap replicate built on the device
+// This file holds the context, the launch logic and the C ABI (include/tetrad_hip.h).
 //
 // Bounds: the scan is L2 / LDS-atomic / VALU work on a <= 40 MB resident matrix (HBM only on
-// first touch), the SVD is f64 VALU.  Algorithmic bytes per quartet: 4*S + 48.
+// first touch), the singular-value stage is f64 VALU.  Algorithmic bytes per quartet: 4*S + 48
+// (SURVEY.md 8d).  DESIGN.md section 4 has the per-kernel description and measurements.
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
 
@@ -47,1346 +41,12 @@
 
 namespace {
 
-constexpr int WAVE = 64;
-constexpr int SITES_PER_LANE = 32;
-constexpr int TILE = WAVE * SITES_PER_LANE;        // 2048 sites per wave step
-constexpr int QPW = 4;                              // quartets per wave pass of the SVD kernel
-constexpr double F64_EPS = 2.220446049250313e-16;
-constexpr double JTOL2 = 7.888609052210118e-31;     // (2^-50)^2 : rotate while g^2 > JTOL2*a*b
-constexpr double JEARLY2 = 1e-10;                   // (1e-5)^2 : see jacobi16
-constexpr int MAX_SWEEPS = 30;
-constexpr double DEGENERATE_REL_GAP = 1e-9;
-
-struct DevData {
-    const uint8_t *rows;
-    const uint4 *planes;
-    int64_t pitch;      // bytes per row (Sp)
-    int64_t W;          // plane records per row (Sp/32)
-    int32_t T;
-    int32_t ntiles;     // Sp / TILE
-};
-
-// Byte offset of site s inside a row.  A 2048-site step is stored as two 1 KiB panels: panel 0
-// holds sites 0-15 of every lane's 32-site group, panel 1 holds sites 16-31, so each of the two
-// 16-byte loads a lane issues per row is part of one fully contiguous 1 KiB wave access.
-__host__ __device__ __forceinline__ int64_t row_offset(int64_t s)
-{
-    const int64_t tile = s >> 11, r = s & 2047, lane = r >> 5, k = r & 31;
-    return (tile << 11) + ((k >> 4) << 10) + (lane << 4) + (k & 15);
-}
-
-struct OutPtrs {
-    uint32_t *rstat;    // [Q,2]
-    double *rscor;      // [Q,3]
-    uint8_t *flags;     // [Q] or null
-    uint32_t *cmats;    // [Q,3,16,16] or null (debug)
-    double *svds;       // [Q,3,16] or null (debug)
-    int32_t *ranks;     // [Q,3] or null (debug)
-};
-
-// ------------------------------------------------------------------------------------
-// data preparation kernel: one thread per 32-site word of one taxon row
-// ------------------------------------------------------------------------------------
-__global__ void tq_prepare_rows(const uint8_t *__restrict__ raw, const uint32_t *__restrict__ locus,
-                                int64_t S, int64_t Sp, int64_t W, int32_t T, uint8_t *__restrict__ rows,
-                                uint4 *__restrict__ planes)
-{
-    int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid >= (int64_t)T * W) return;
-    int64_t t = gid / W, w = gid - t * W;
-    const uint8_t *src = raw + t * S + w * 32;
-    uint8_t *dst = rows + t * Sp;
-    uint32_t mm = 0, b0 = 0, b1 = 0, rb = 0;
-    for (int i = 0; i < 32; ++i) {
-        int64_t s = w * 32 + i;
-        uint8_t v = (s < S) ? src[i] : (uint8_t)0xFF;
-        bool missing = v > 3;
-        uint8_t code = missing ? (uint8_t)0 : v;
-        dst[row_offset(s)] = code;
-        mm |= (uint32_t)missing << i;
-        b0 |= (uint32_t)(code & 1) << i;
-        b1 |= (uint32_t)((code >> 1) & 1) << i;
-        if (s < S) {
-            bool beg = (s == 0) || (locus[s] != locus[s - 1]);
-            rb |= (uint32_t)beg << i;
-        }
-    }
-    planes[t * W + w] = make_uint4(mm, b0, b1, rb);
-}
-
-// ------------------------------------------------------------------------------------
-// lexicographic unranking of 4-combinations (combinations.py:94-106)
-// ------------------------------------------------------------------------------------
-__device__ __forceinline__ uint64_t choose_k(uint64_t n, int k)
-{
-    switch (k) {
-    case 0: return 1;
-    case 1: return n;
-    case 2: return n < 2 ? 0 : n * (n - 1) / 2;
-    default: return n < 3 ? 0 : n * (n - 1) / 2 * (n - 2) / 3;
-    }
-}
-
-__global__ void tq_unrank_kernel(const uint64_t *__restrict__ ranks, uint64_t first_rank, int64_t Q,
-                                 int32_t T, uint32_t *__restrict__ quartets)
-{
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= Q) return;
-    uint64_t index = ranks ? ranks[i] : first_rank + (uint64_t)i;
-    uint32_t out[4] = {0, 0, 0, 0};
-    int nsel = 0;
-    for (int t = 0; t < T && nsel < 4; ++t) {
-        uint64_t c = choose_k((uint64_t)(T - t - 1), 4 - nsel - 1);
-        if (c > index) {
-            out[nsel++] = (uint32_t)t;
-        } else {
-            index -= c;
-        }
-    }
-    uint4 v = make_uint4(out[0], out[1], out[2], out[3]);
-    reinterpret_cast<uint4 *>(quartets)[i] = v;
-}
-
-// sort key of a quartet: its first two taxa (quartets sharing them share two of their four rows)
-__global__ void tq_key_kernel(const uint32_t *__restrict__ quartets, int64_t Q, uint32_t T,
-                              uint32_t *__restrict__ keys, uint32_t *__restrict__ idx)
-{
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= Q) return;
-    const uint4 q = reinterpret_cast<const uint4 *>(quartets)[i];
-    const uint32_t a = q.x < T ? q.x : T - 1, b = q.y < T ? q.y : T - 1;
-    keys[i] = a * T + b;
-    idx[i] = (uint32_t)i;
-}
-
-// ------------------------------------------------------------------------------------
-// kernel 1: site scan -> 256-bin pattern histogram
-// ------------------------------------------------------------------------------------
-struct TileRegs {
-    uint4 a0, a1, b0, b1, c0, c1, d0, d1;   // 32 site bytes of each of the four rows
-    uint4 pa, pb, pc, pd;                    // plane records {miss, p0, p1, runbeg} of the four rows
-};
-
-__device__ __forceinline__ void load_tile(TileRegs &r, const DevData &d, const uint32_t (&q)[4], int tile,
-                                          int lane)
-{
-    const int64_t boff = (int64_t)tile * TILE + lane * 16;            // panel layout: see row_offset
-    const uint4 *pa = reinterpret_cast<const uint4 *>(d.rows + (int64_t)q[0] * d.pitch + boff);
-    const uint4 *pb = reinterpret_cast<const uint4 *>(d.rows + (int64_t)q[1] * d.pitch + boff);
-    const uint4 *pc = reinterpret_cast<const uint4 *>(d.rows + (int64_t)q[2] * d.pitch + boff);
-    const uint4 *pd = reinterpret_cast<const uint4 *>(d.rows + (int64_t)q[3] * d.pitch + boff);
-    r.a0 = pa[0]; r.a1 = pa[64];
-    r.b0 = pb[0]; r.b1 = pb[64];
-    r.c0 = pc[0]; r.c1 = pc[64];
-    r.d0 = pd[0]; r.d1 = pd[64];
-    const int64_t woff = (int64_t)tile * WAVE + lane;
-    r.pa = d.planes[(int64_t)q[0] * d.W + woff];
-    r.pb = d.planes[(int64_t)q[1] * d.W + woff];
-    r.pc = d.planes[(int64_t)q[2] * d.W + woff];
-    r.pd = d.planes[(int64_t)q[3] * d.W + woff];
-}
-
-// Sites to count among this lane's 32 (bit i = site i).
-//   U = variable among the four taxa and none missing (resolve_quartets.py:216-218).
-//   full mode      : C = U.
-//   subsample mode : C = sites of U that are the first unmasked site of their locus run
-//                    (resolve_quartets.py:58-64: a site is counted iff unmasked and its locus
-//                    differs from the locus of the previous unmasked site).  seen(i) = "an
-//                    unmasked site precedes i in the same run" obeys
-//                    t(i) = U(i) | (P(i) & t(i-1)), P = ~runbegin, seen(i) = P(i) & t(i-1),
-//                    which is the carry recurrence of the addition (U|P) + U.
-template <bool SUB>
-__device__ __forceinline__ uint32_t count_mask(const TileRegs &r, int lane, uint32_t &tile_carry)
-{
-    const uint32_t M = r.pa.x | r.pb.x | r.pc.x | r.pd.x;
-    const uint32_t V = (r.pa.y ^ r.pb.y) | (r.pa.z ^ r.pb.z) | (r.pa.y ^ r.pc.y) | (r.pa.z ^ r.pc.z) |
-                       (r.pa.y ^ r.pd.y) | (r.pa.z ^ r.pd.z);
-    const uint32_t U = V & ~M;
-    if (!SUB) return U;
-    const uint32_t B = r.pa.w;
-    const uint32_t P = ~B;
-    const uint32_t X = U | P;
-    const uint32_t sum = X + U;
-    const uint32_t cin0 = sum ^ X ^ U;                       // carry into each bit, lane carry-in = 0
-    const uint32_t seen_local = P & cin0;
-    const uint32_t gen = ((X & U) | ((X | U) & ~sum)) >> 31; // carry out of bit 31 = t(31)
-    // cross-lane: T(l) = gen(l) | (allprop(l) & T(l-1)); same adder trick on 64-bit ballots (SALU)
-    const uint64_t Gm = __ballot(gen != 0);
-    const uint64_t Pm = __ballot(B == 0);
-    const uint64_t Xm = Gm | Pm;
-    const uint64_t s1 = Xm + Gm;
-    const uint64_t s2 = s1 + (uint64_t)tile_carry;
-    const uint64_t cinm = s2 ^ Xm ^ Gm;                      // carry into each lane
-    tile_carry = (uint32_t)((s1 < Xm) | (s2 < s1));          // carry out of lane 63
-    const uint32_t cin = (uint32_t)(cinm >> lane) & 1u;
-    // sites before this lane's first run-begin inherit the incoming "seen" state
-    const uint32_t firstseg = B ? ((B & (0u - B)) - 1u) : 0xFFFFFFFFu;
-    const uint32_t seen = seen_local | (cin ? firstseg : 0u);
-    return U & ~seen;
-}
-
-// four sites (one dword of each row): EXEC-masked histogram increments for the counted ones
-template <int NREP>
-__device__ __forceinline__ void hist_dword(uint32_t a, uint32_t b, uint32_t c, uint32_t d, uint32_t C, int site0,
-                                           uint32_t *hrep)
-{
-    // base codes are 0..3, so the per-byte pattern (a<<6|b<<4|c<<2|d) never crosses a byte
-    const uint32_t pat = (((((a << 2) + b) << 2) + c) << 2) + d;     // fields never overlap: + == |, one v_lshl_add each
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        if (C & (1u << (site0 + k)))
-            __hip_atomic_fetch_add(&hrep[((pat >> (8 * k)) & 0xFFu) * NREP], 1u, __ATOMIC_RELAXED,
-                                   __HIP_MEMORY_SCOPE_WORKGROUP);
-    }
-}
-
-// METHOD 0: one EXEC-masked ds_add per site slot (32 per step, whatever the density).
-// METHOD 1: the lane parks its 32 pattern bytes in LDS and walks the set bits of C: the number of
-//           ds_add per step is the largest per-lane count in the wave (~10 of 32 in subsample
-//           mode, where at most one site per locus run is counted).
-constexpr int PAT_STRIDE = 36;   // bytes per lane in the pattern park (9 dwords: conflict-free b32 stores)
-
-template <int NREP, bool SUB, int METHOD>
-__device__ __forceinline__ void process_tile(const TileRegs &t, int lane, uint32_t &tile_carry, uint32_t *hrep,
-                                             uint8_t *park)
-{
-    const uint32_t C = count_mask<SUB>(t, lane, tile_carry);
-    if (METHOD == 2) {          // timing diagnostic: everything but the histogram (results are wrong)
-#define TQ_PAT(a, b, c, d) (((((((a) << 2) + (b)) << 2) + (c)) << 2) + (d))
-        uint32_t acc = C;
-        acc ^= TQ_PAT(t.a0.x, t.b0.x, t.c0.x, t.d0.x) ^ TQ_PAT(t.a0.y, t.b0.y, t.c0.y, t.d0.y);
-        acc ^= TQ_PAT(t.a0.z, t.b0.z, t.c0.z, t.d0.z) ^ TQ_PAT(t.a0.w, t.b0.w, t.c0.w, t.d0.w);
-        acc ^= TQ_PAT(t.a1.x, t.b1.x, t.c1.x, t.d1.x) ^ TQ_PAT(t.a1.y, t.b1.y, t.c1.y, t.d1.y);
-        acc ^= TQ_PAT(t.a1.z, t.b1.z, t.c1.z, t.d1.z) ^ TQ_PAT(t.a1.w, t.b1.w, t.c1.w, t.d1.w);
-#undef TQ_PAT
-        asm volatile("" ::"v"(acc));
-    } else if (METHOD == 0) {
-        hist_dword<NREP>(t.a0.x, t.b0.x, t.c0.x, t.d0.x, C, 0, hrep);
-        hist_dword<NREP>(t.a0.y, t.b0.y, t.c0.y, t.d0.y, C, 4, hrep);
-        hist_dword<NREP>(t.a0.z, t.b0.z, t.c0.z, t.d0.z, C, 8, hrep);
-        hist_dword<NREP>(t.a0.w, t.b0.w, t.c0.w, t.d0.w, C, 12, hrep);
-        hist_dword<NREP>(t.a1.x, t.b1.x, t.c1.x, t.d1.x, C, 16, hrep);
-        hist_dword<NREP>(t.a1.y, t.b1.y, t.c1.y, t.d1.y, C, 20, hrep);
-        hist_dword<NREP>(t.a1.z, t.b1.z, t.c1.z, t.d1.z, C, 24, hrep);
-        hist_dword<NREP>(t.a1.w, t.b1.w, t.c1.w, t.d1.w, C, 28, hrep);
-    } else {
-        uint32_t *pw = reinterpret_cast<uint32_t *>(park);
-#define TQ_PAT(a, b, c, d) (((((((a) << 2) + (b)) << 2) + (c)) << 2) + (d))
-        pw[0] = TQ_PAT(t.a0.x, t.b0.x, t.c0.x, t.d0.x);
-        pw[1] = TQ_PAT(t.a0.y, t.b0.y, t.c0.y, t.d0.y);
-        pw[2] = TQ_PAT(t.a0.z, t.b0.z, t.c0.z, t.d0.z);
-        pw[3] = TQ_PAT(t.a0.w, t.b0.w, t.c0.w, t.d0.w);
-        pw[4] = TQ_PAT(t.a1.x, t.b1.x, t.c1.x, t.d1.x);
-        pw[5] = TQ_PAT(t.a1.y, t.b1.y, t.c1.y, t.d1.y);
-        pw[6] = TQ_PAT(t.a1.z, t.b1.z, t.c1.z, t.d1.z);
-        pw[7] = TQ_PAT(t.a1.w, t.b1.w, t.c1.w, t.d1.w);
-#undef TQ_PAT
-        // set-bit walk, software pipelined: the pattern byte of the NEXT counted site is requested
-        // before the histogram increment of the current one, so the LDS read latency of one step
-        // hides behind the previous step instead of stalling every iteration
-        uint32_t c = C;
-        if (c) {
-            // two alternating registers instead of a copy: a copy would wait for the read it copies
-            uint32_t b0 = park[__builtin_ctz(c)], b1 = 0;
-            c &= c - 1;
-            for (;;) {
-                if (!c) {
-                    __hip_atomic_fetch_add(&hrep[b0 * NREP], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    break;
-                }
-                b1 = park[__builtin_ctz(c)];
-                c &= c - 1;
-                __hip_atomic_fetch_add(&hrep[b0 * NREP], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                if (!c) {
-                    __hip_atomic_fetch_add(&hrep[b1 * NREP], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    break;
-                }
-                b0 = park[__builtin_ctz(c)];
-                c &= c - 1;
-                __hip_atomic_fetch_add(&hrep[b1 * NREP], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            }
-        }
-    }
-}
-
-// Double-buffered scan: the loads of step t+1 are issued before step t is processed; the
-// sched_barriers keep the compiler from sinking them next to their first use.  The prefetch is
-// unconditional (the index is clamped, so the last step re-reads its own tile): a conditional
-// load would make the compiler merge the buffers with copies that wait for the loads at once.
-template <int NREP, bool SUB, int METHOD>
-__device__ __forceinline__ void scan_quartet(const DevData &d, const uint32_t (&q)[4], uint32_t *hist,
-                                             uint8_t *park, int lane)
-{
-    uint32_t *hrep = hist + (lane & (NREP - 1));
-    uint32_t tile_carry = 0;
-    const int last = d.ntiles - 1;
-    TileRegs A, B;
-    load_tile(A, d, q, 0, lane);
-    for (int t = 0; t < d.ntiles; t += 2) {
-        load_tile(B, d, q, min(t + 1, last), lane);
-        __builtin_amdgcn_sched_barrier(0);
-        process_tile<NREP, SUB, METHOD>(A, lane, tile_carry, hrep, park);
-        __builtin_amdgcn_sched_barrier(0);
-        if (t + 1 >= d.ntiles) break;
-        load_tile(A, d, q, min(t + 2, last), lane);
-        __builtin_amdgcn_sched_barrier(0);
-        process_tile<NREP, SUB, METHOD>(B, lane, tile_carry, hrep, park);
-        __builtin_amdgcn_sched_barrier(0);
-    }
-}
-
-// cm layout: u32 [Q][256], cm[q][64*i0 + 16*i1 + 4*i2 + i3] = number of counted sites with pattern
-// (i0,i1,i2,i3) -- i.e. mats[0] of resolve_quartets.py:55-64 / :89-95 in row-major order.
-template <int NREP, bool SUB, int METHOD>
-__global__ void __launch_bounds__(WAVE)
-tq_scan_kernel(DevData d, const uint32_t *__restrict__ quartets, const uint32_t *__restrict__ order, int64_t Q,
-               uint32_t *__restrict__ cm)
-{
-    __shared__ uint32_t hist[256 * NREP + (METHOD ? WAVE * PAT_STRIDE / 4 : 0)];
-    const int lane = threadIdx.x;
-    uint8_t *park = reinterpret_cast<uint8_t *>(hist + 256 * NREP) + lane * PAT_STRIDE;
-    for (int i = lane; i < 256 * NREP; i += WAVE) hist[i] = 0;
-    __syncthreads();
-    for (int64_t it = blockIdx.x; it < Q; it += gridDim.x) {
-        // waves that run together work on neighbours of the (a,b)-sorted order, so rows a and b
-        // are L2 hits for all of them; results go to the quartet's original slot
-        const int64_t qi = order ? (int64_t)order[it] : it;
-        const uint4 qv = reinterpret_cast<const uint4 *>(quartets)[qi];
-        uint32_t q[4];
-        q[0] = __builtin_amdgcn_readfirstlane(qv.x);
-        q[1] = __builtin_amdgcn_readfirstlane(qv.y);
-        q[2] = __builtin_amdgcn_readfirstlane(qv.z);
-        q[3] = __builtin_amdgcn_readfirstlane(qv.w);
-        const uint32_t T = (uint32_t)d.T;
-        const bool bad = (q[0] >= T) | (q[1] >= T) | (q[2] >= T) | (q[3] >= T);
-        uint32_t *out = cm + qi * 256;
-        if (bad) {                              // flagged by the SVD kernel; never dereferenced
-#pragma unroll
-            for (int k = 0; k < 4; ++k) out[lane + WAVE * k] = 0;
-            continue;
-        }
-        scan_quartet<NREP, SUB, METHOD>(d, q, hist, park, lane);
-        __syncthreads();
-        // fold the replicas, clear them for the next quartet, store the 256 counts (coalesced)
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int bin = lane + WAVE * k;
-            uint32_t s = 0;
-#pragma unroll
-            for (int r = 0; r < NREP; ++r) {
-                const int rr = (r + lane) & (NREP - 1);
-                s += hist[bin * NREP + rr];
-                hist[bin * NREP + rr] = 0;
-            }
-            out[bin] = s;
-        }
-        __syncthreads();
-    }
-}
-
-
-// ------------------------------------------------------------------------------------
-// kernel 1, workgroup-cooperative form: NW wavefronts = NW neighbours of the (a,b)-sorted order.
-// Quartets that share their first two taxa share two of their four rows, so the workgroup fetches
-// the rows (and plane records) of taxa a and b ONCE per 2048-site step into LDS (all NW*64 threads
-// cooperate: 384 x 16 B), double-buffered with one barrier per step; every wave still streams its
-// own rows c and d straight to registers.  Cache traffic per quartet falls from 12 KiB to
-// 6 + 6/NW KiB per step -- the scan kernel is L2 / Infinity-Cache bandwidth bound.  A wave whose
-// (a,b) differs from the leader's (group boundary in the sorted order) reads its own a and b
-// from global memory instead; it still takes part in the loads and barriers.
-// ------------------------------------------------------------------------------------
-struct OwnRegs {
-    uint4 c0, c1, d0, d1, pc, pd;
-};
-
-// 16-byte load at a wave-uniform base + 32-bit per-lane byte offset (lets the compiler use the
-// SGPR-base addressing form instead of 64-bit VGPR pointer arithmetic for every load; the host
-// guarantees T*Sp < 2^32 before it selects this kernel)
-__device__ __forceinline__ uint4 ld16(const uint8_t *base, uint32_t off)
-{
-    return *reinterpret_cast<const uint4 *>(base + off);
-}
-
-// per-lane byte offsets of a wave's own rows c, d (rows array) and their plane records
-struct OwnOff {
-    uint32_t c, d, pc, pd;
-};
-
-__device__ __forceinline__ void load_own(OwnRegs &r, const uint8_t *rows, const uint8_t *planes, const OwnOff &o,
-                                         int tile)
-{
-    const uint32_t tb = (uint32_t)tile * TILE, tp = (uint32_t)tile * (WAVE * 16);
-    r.c0 = ld16(rows, o.c + tb);
-    r.c1 = ld16(rows, o.c + tb + 1024);
-    r.d0 = ld16(rows, o.d + tb);
-    r.d1 = ld16(rows, o.d + tb + 1024);
-    r.pc = ld16(planes, o.pc + tp);
-    r.pd = ld16(planes, o.pd + tp);
-}
-
-constexpr int SHARED_PIECES = 384;   // uint4 per step: row a 128, row b 128, planes a 64, planes b 64
-
-template <bool SUB, int METHOD, int NW>
-__global__ void __launch_bounds__(NW *WAVE)
-tq_scan_wg_kernel(DevData d, const uint32_t *__restrict__ quartets, const uint32_t *__restrict__ order, int64_t Q,
-                  uint32_t *__restrict__ cm)
-{
-    static_assert(NW * WAVE >= SHARED_PIECES, "one cooperative piece per thread");
-    __shared__ uint4 shared_ab[2][SHARED_PIECES];
-    __shared__ uint32_t hist_all[NW][256];
-    __shared__ uint32_t park_all[NW][WAVE * PAT_STRIDE / 4];
-    const int tid = threadIdx.x;
-    const int w = tid >> 6;
-    const int lane = tid & 63;
-    uint32_t *hist = hist_all[w];
-    uint8_t *park = reinterpret_cast<uint8_t *>(park_all[w]) + lane * PAT_STRIDE;
-    for (int i = lane; i < 256; i += WAVE) hist[i] = 0;
-    const uint32_t T = (uint32_t)d.T;
-    const int last = d.ntiles - 1;
-    const int64_t nblk = (Q + NW - 1) / NW;
-    const uint8_t *rows = d.rows;
-    const uint8_t *planes = reinterpret_cast<const uint8_t *>(d.planes);
-    const uint32_t pitch = (uint32_t)d.pitch, wpitch = (uint32_t)d.W * 16u;
-    // this thread's cooperative piece: waves 0-3 fetch row bytes of a / b, waves 4-5 plane records
-    const uint8_t *sh_base = tid < 256 ? rows : planes;                       // wave-uniform
-    const uint32_t sh_step = tid < 256 ? (uint32_t)TILE : (uint32_t)(WAVE * 16);
-    const uint32_t sh_lane = tid < 256 ? (uint32_t)(tid & 127) * 16u : (uint32_t)((tid - 256) & 63) * 16u;
-    const bool sh_is_b = tid < 256 ? (tid >= 128) : (tid >= 320);
-    __syncthreads();
-
-    for (int64_t blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
-        // leader = first quartet of the block; its (a,b) is what the workgroup shares
-        const int64_t it0 = blk * NW;
-        const int64_t lqi = order ? (int64_t)order[it0] : it0;
-        const uint4 lq = reinterpret_cast<const uint4 *>(quartets)[lqi];
-        uint32_t la = __builtin_amdgcn_readfirstlane(lq.x), lb = __builtin_amdgcn_readfirstlane(lq.y);
-        const bool leader_ok = (la < T) & (lb < T);
-        if (!leader_ok) la = lb = 0;
-        // this wave's quartet
-        const int64_t it = it0 + w;
-        const bool have = it < Q;
-        const int64_t qi = have ? (order ? (int64_t)order[it] : it) : 0;
-        const uint4 qv = reinterpret_cast<const uint4 *>(quartets)[qi];
-        uint32_t q[4];
-        q[0] = __builtin_amdgcn_readfirstlane(qv.x);
-        q[1] = __builtin_amdgcn_readfirstlane(qv.y);
-        q[2] = __builtin_amdgcn_readfirstlane(qv.z);
-        q[3] = __builtin_amdgcn_readfirstlane(qv.w);
-        const bool bad = (q[0] >= T) | (q[1] >= T) | (q[2] >= T) | (q[3] >= T);
-        const bool work = have && !bad;                     // wave-uniform
-        const bool shares = work && leader_ok && q[0] == la && q[1] == lb;
-        const uint32_t qc = work ? q[2] : 0, qd = work ? q[3] : 0;
-        OwnOff oo;
-        oo.c = qc * pitch + (uint32_t)lane * 16u;
-        oo.d = qd * pitch + (uint32_t)lane * 16u;
-        oo.pc = qc * wpitch + (uint32_t)lane * 16u;
-        oo.pd = qd * wpitch + (uint32_t)lane * 16u;
-        const uint32_t sh_off = (sh_is_b ? lb : la) * (tid < 256 ? pitch : wpitch) + sh_lane;
-
-        // prologue: step 0 into buffer 0
-        const int slot = tid;     // rows are stored in panels already (row_offset), so piece p is slot p
-        if (tid < SHARED_PIECES) shared_ab[0][slot] = ld16(sh_base, sh_off);
-        OwnRegs A, B;
-        load_own(A, rows, planes, oo, 0);
-        uint32_t tile_carry = 0;
-        __syncthreads();
-
-        auto step = [&](const OwnRegs &own, int t) {
-            TileRegs r;
-            if (shares) {
-                const uint4 *buf = shared_ab[t & 1];
-                r.a0 = buf[lane];
-                r.a1 = buf[64 + lane];
-                r.b0 = buf[128 + lane];
-                r.b1 = buf[192 + lane];
-                r.pa = buf[256 + lane];
-                r.pb = buf[320 + lane];
-            } else if (work) {                               // group boundary: private rows a and b
-                const int64_t boff = (int64_t)t * TILE + lane * 16;
-                const uint4 *pa = reinterpret_cast<const uint4 *>(d.rows + (int64_t)q[0] * d.pitch + boff);
-                const uint4 *pb = reinterpret_cast<const uint4 *>(d.rows + (int64_t)q[1] * d.pitch + boff);
-                r.a0 = pa[0]; r.a1 = pa[64];
-                r.b0 = pb[0]; r.b1 = pb[64];
-                const int64_t woff = (int64_t)t * WAVE + lane;
-                r.pa = d.planes[(int64_t)q[0] * d.W + woff];
-                r.pb = d.planes[(int64_t)q[1] * d.W + woff];
-            }
-            if (work) {
-                r.c0 = own.c0; r.c1 = own.c1;
-                r.d0 = own.d0; r.d1 = own.d1;
-                r.pc = own.pc; r.pd = own.pd;
-                process_tile<1, SUB, METHOD>(r, lane, tile_carry, hist, park);
-            }
-        };
-
-        for (int t = 0; t < d.ntiles; t += 2) {
-            // ---- even step: prefetch t+1 (own -> B, shared -> registers), process A ----
-            {
-                const int tn = min(t + 1, last);
-                uint4 sh = make_uint4(0, 0, 0, 0);
-                if (tid < SHARED_PIECES) sh = ld16(sh_base, sh_off + (uint32_t)tn * sh_step);
-                load_own(B, rows, planes, oo, tn);
-                __builtin_amdgcn_sched_barrier(0);
-                step(A, t);
-                __builtin_amdgcn_sched_barrier(0);
-                if (tid < SHARED_PIECES) shared_ab[(t + 1) & 1][slot] = sh;
-                __syncthreads();
-            }
-            if (t + 1 >= d.ntiles) break;
-            // ---- odd step ----
-            {
-                const int tn = min(t + 2, last);
-                uint4 sh = make_uint4(0, 0, 0, 0);
-                if (tid < SHARED_PIECES) sh = ld16(sh_base, sh_off + (uint32_t)tn * sh_step);
-                load_own(A, rows, planes, oo, tn);
-                __builtin_amdgcn_sched_barrier(0);
-                step(B, t + 1);
-                __builtin_amdgcn_sched_barrier(0);
-                if (tid < SHARED_PIECES) shared_ab[t & 1][slot] = sh;
-                __syncthreads();
-            }
-        }
-        // store the 256 counts of this wave's quartet and clear its histogram
-        if (have) {
-            uint32_t *out = cm + qi * 256;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int bin = lane + WAVE * k;
-                out[bin] = work ? hist[bin] : 0u;
-                hist[bin] = 0;
-            }
-        }
-        __syncthreads();
-    }
-}
-
-// ------------------------------------------------------------------------------------
-// kernel 2: singular values of a 16x16 matrix, one column per lane of a 16-lane group
-// ------------------------------------------------------------------------------------
-__device__ __forceinline__ double shx(double v, int m) { return __shfl_xor(v, m, WAVE); }
-
-// XOR-partner exchange inside a 16-lane row with DPP moves (VALU) instead of ds_bpermute_b32:
-// the LDS crossbar is one unit per CU and a bpermute holds it for 4 cycles, which made the SVD
-// stage LDS-issue bound (profiles/r01_v1_baseline).  gfx9 DPP offers the involutions
-// quad_perm (lane^1, ^2, ^3), row_half_mirror (lane^7), row_ror:8 (lane^8), row_mirror (lane^15);
-// every other XOR mask is a product of two of them.
-template <int CTRL>
-__device__ __forceinline__ int dpp_mov(int v)
-{
-    return __builtin_amdgcn_mov_dpp(v, CTRL, 0xF, 0xF, true);
-}
-
-template <int Q>
-__device__ __forceinline__ int dpp_quad_xor(int v)
-{
-    static_assert(Q >= 1 && Q <= 3, "quad xor");
-    return Q == 1 ? dpp_mov<0xB1>(v) : Q == 2 ? dpp_mov<0x4E>(v) : dpp_mov<0x1B>(v);
-}
-
-template <int M>
-__device__ __forceinline__ int dpp_xor16(int v)
-{
-    static_assert(M >= 1 && M <= 15, "xor mask within a 16-lane row");
-    constexpr int DPP_ROW_MIRROR = 0x140, DPP_ROW_HALF_MIRROR = 0x141, DPP_ROW_ROR8 = 0x128;
-    if constexpr (M == 15) return dpp_mov<DPP_ROW_MIRROR>(v);
-    else if constexpr (M == 7) return dpp_mov<DPP_ROW_HALF_MIRROR>(v);
-    else if constexpr (M == 8) return dpp_mov<DPP_ROW_ROR8>(v);
-    else if constexpr (M >= 12) return dpp_quad_xor<(M & 3) ^ 3>(dpp_mov<DPP_ROW_MIRROR>(v));
-    else if constexpr (M >= 9) return dpp_quad_xor<M & 3>(dpp_mov<DPP_ROW_ROR8>(v));
-    else if constexpr (M >= 4) return dpp_quad_xor<(M & 3) ^ 3>(dpp_mov<DPP_ROW_HALF_MIRROR>(v));
-    else return dpp_quad_xor<M>(v);
-}
-
-template <int M>
-__device__ __forceinline__ double dpx(double v)
-{
-    const int lo = dpp_xor16<M>(__double2loint(v));
-    const int hi = dpp_xor16<M>(__double2hiint(v));
-    return __hiloint2double(hi, lo);
-}
-
-template <int M>
-__device__ __forceinline__ void exchange_col(const double (&a)[16], double nrm, double (&b)[16], double &nb)
-{
-#pragma unroll
-    for (int r = 0; r < 16; ++r) b[r] = dpx<M>(a[r]);
-    nb = dpx<M>(nrm);
-}
-
-__device__ __forceinline__ double group_max(double v)
-{
-#pragma unroll
-    for (int m = 1; m < 16; m <<= 1) v = fmax(v, shx(v, m));
-    return v;
-}
-
-__device__ __forceinline__ double group_sum(double v)
-{
-#pragma unroll
-    for (int m = 1; m < 16; m <<= 1) v += shx(v, m);
-    return v;
-}
-
-struct SvResult {
-    double sigma;   // this lane's singular value
-    int pos;        // its 0-based position in descending order
-    int rank;       // numpy.linalg.matrix_rank rule on the group's 16 values
-    double smax;
-};
-
-// f64 reciprocal / reciprocal square root from the hardware estimate (v_rcp_f64 / v_rsq_f64)
-// plus Newton steps.  NR = 1 gives >= ~2^-45 (enough for the rotation tangent, whose error only
-// affects convergence speed), NR = 2 gives full f64 precision (needed for the cosine, which
-// scales the columns and therefore the singular values).  tools/probe_math.hip measures both.
-template <int NR>
-__device__ __forceinline__ double rcp_nr(double v)
-{
-    double r = __builtin_amdgcn_rcp(v);
-#pragma unroll
-    for (int i = 0; i < NR; ++i) r = fma(fma(-v, r, 1.0), r, r);
-    return r;
-}
-
-template <int NR>
-__device__ __forceinline__ double rsq_nr(double v)
-{
-    double y = __builtin_amdgcn_rsq(v);
-#pragma unroll
-    for (int i = 0; i < NR; ++i) y = fma(0.5 * y, fma(-v * y, y, 1.0), y);
-    return y;
-}
-
-// One-sided Jacobi, XOR-partner ordering.  Mirrors tests/jacobi_model.py step for step.
-//   rotation of the pair (p,q), p < q, alpha = |a_p|^2, beta = |a_q|^2, g = a_p.a_q:
-//     d = beta - alpha, h = 2g, t = sign(d) * h / (|d| + sqrt(d^2 + h^2))   (smaller root)
-//     c = 1/sqrt(1 + t^2), s = c*t ;  a_p <- c*a_p - s*a_q ;  a_q <- s*a_p + c*a_q
-//   a pair is rotated while g^2 > JTOL2*alpha*beta; a sweep in which no pair exceeded
-//   JEARLY2 before its rotation is the last one (quadratic convergence squares the
-//   remaining off-diagonal, (1e-5)^2 << 2^-50, so the verification sweep is skipped).
-__device__ __forceinline__ SvResult jacobi16(double (&a)[16], int j, int lane)
-{
-    // a 16-lane group stops rotating when ITS matrix has converged, whatever the other three
-    // groups of the wave still do: results do not depend on which quartets share a wave
-    bool active = true;
-    for (int sweep = 0; sweep < MAX_SWEEPS; ++sweep) {
-        double nrm = 0.0;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) nrm = fma(a[r], a[r], nrm);
-        // columns below eps * (largest column norm) are numerically zero: frozen, not rotated
-        const double zthr = (F64_EPS * F64_EPS) * group_max(nrm);
-        bool again = false;
-#pragma unroll 1
-        for (int m = 1; m < 16; ++m) {
-            double b[16];
-            double nb;
-            switch (m) {                       // wave-uniform: one scalar branch per round
-            case 1: exchange_col<1>(a, nrm, b, nb); break;
-            case 2: exchange_col<2>(a, nrm, b, nb); break;
-            case 3: exchange_col<3>(a, nrm, b, nb); break;
-            case 4: exchange_col<4>(a, nrm, b, nb); break;
-            case 5: exchange_col<5>(a, nrm, b, nb); break;
-            case 6: exchange_col<6>(a, nrm, b, nb); break;
-            case 7: exchange_col<7>(a, nrm, b, nb); break;
-            case 8: exchange_col<8>(a, nrm, b, nb); break;
-            case 9: exchange_col<9>(a, nrm, b, nb); break;
-            case 10: exchange_col<10>(a, nrm, b, nb); break;
-            case 11: exchange_col<11>(a, nrm, b, nb); break;
-            case 12: exchange_col<12>(a, nrm, b, nb); break;
-            case 13: exchange_col<13>(a, nrm, b, nb); break;
-            case 14: exchange_col<14>(a, nrm, b, nb); break;
-            default: exchange_col<15>(a, nrm, b, nb); break;
-            }
-            double g0 = 0.0, g1 = 0.0;
-#pragma unroll
-            for (int r = 0; r < 16; r += 2) {
-                g0 = fma(a[r], b[r], g0);
-                g1 = fma(a[r + 1], b[r + 1], g1);
-            }
-            const double g = g0 + g1;
-            const bool lo = j < (j ^ m);
-            const double alpha = lo ? nrm : nb;
-            const double beta = lo ? nb : nrm;
-            const double ab = alpha * beta;
-            const double gg = g * g;
-            const bool live = fmin(alpha, beta) > zthr;
-            const bool doit = active && live && (gg > JTOL2 * ab);
-            again |= live && (gg > JEARLY2 * ab);
-            if (__any(doit)) {
-                const double d = beta - alpha;
-                const double h = doit ? g + g : 1.0;
-                const double x = fma(d, d, h * h);
-                const double rr = x * rsq_nr<1>(x);                    // sqrt(d^2 + h^2)
-                const double tt = h * rcp_nr<1>(fabs(d) + rr);
-                const double t = (d < 0.0) ? -tt : tt;
-                double c = rsq_nr<2>(fma(t, t, 1.0));
-                double sg = lo ? -(c * t) : (c * t);
-                c = doit ? c : 1.0;
-                sg = doit ? sg : 0.0;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) a[r] = fma(sg, b[r], c * a[r]);
-                const double tg = doit ? t * g : 0.0;
-                nrm = fmax(lo ? nrm - tg : nrm + tg, 0.0);
-            }
-        }
-        active = active && (((__ballot(again) >> (lane & 48)) & 0xFFFFull) != 0);
-        if (!__any(active)) break;
-    }
-    double nrm = 0.0;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) nrm = fma(a[r], a[r], nrm);
-    SvResult o;
-    o.sigma = sqrt(nrm);
-    o.smax = group_max(o.sigma);
-    int pos = 0;
-#pragma unroll 1
-    for (int m = 1; m < 16; ++m) {
-        const double other = shx(o.sigma, m);
-        const int k = j ^ m;
-        pos += (other > o.sigma) || (other == o.sigma && k < j);
-    }
-    o.pos = pos;
-    // numpy.linalg.matrix_rank: count(S > S.max() * max(M,N) * eps)
-    const double thr = o.smax * 16.0 * F64_EPS;
-    const uint64_t bal = __ballot(o.sigma > thr);
-    o.rank = __popcll((bal >> (lane & 48)) & 0xFFFFull);
-    return o;
-}
-
-// bin of element (row r, column j) of flattening t:
-//   t=0: rows (i0,i1) cols (i2,i3);  t=1: rows (i0,i2) cols (i1,i3);  t=2: rows (i0,i3) cols (i1,i2)
-__device__ __forceinline__ int flat_bin(int t, int r, int j)
-{
-    if (t == 0) return 16 * r + j;
-    const int hi = 64 * (r >> 2) + 16 * (j >> 2);
-    if (t == 1) return hi + 4 * (r & 3) + (j & 3);
-    return hi + 4 * (j & 3) + (r & 3);
-}
-
-// kernel 2: count matrices -> singular values, rank, scores, topology
-template <bool DEBUG>
-__global__ void __launch_bounds__(WAVE)
-tq_svd_kernel(const uint32_t *__restrict__ cm, const uint32_t *__restrict__ quartets, int64_t Q, int32_t T,
-              OutPtrs out)
-{
-    __shared__ uint32_t lds[QPW * 256];
-    const int lane = threadIdx.x;
-    const int grp = lane >> 4;      // 16-lane group = quartet slot
-    const int j = lane & 15;        // column owned
-
-    const int64_t npass = (Q + QPW - 1) / QPW;
-    for (int64_t wg = blockIdx.x; wg < npass; wg += gridDim.x) {
-        // stage the four 1 KiB count slabs of this pass through LDS (coalesced 16-byte loads)
-        {
-            const int64_t q0 = wg * QPW;
-            const uint4 *src = reinterpret_cast<const uint4 *>(cm + q0 * 256);
-            uint4 *dst = reinterpret_cast<uint4 *>(lds);
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int idx = lane + WAVE * k;               // 256 uint4 = 4 quartets x 64
-                const bool ok = (q0 + (idx >> 6)) < Q;
-                dst[idx] = ok ? src[idx] : make_uint4(0, 0, 0, 0);
-            }
-        }
-        __syncthreads();
-
-        const int64_t myq = wg * QPW + grp;
-        const uint32_t *cmq = lds + 256 * grp;
-        double sig[3];
-        int pos[3], rnk[3];
-        double smax_all = 0.0;
-        uint32_t my_nsnps = 0;
-#pragma unroll
-        for (int t = 0; t < 3; ++t) {
-            double a[16];
-            uint32_t colsum = 0;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const uint32_t v = cmq[flat_bin(t, r, j)];
-                a[r] = (double)v;
-                colsum += v;
-                if (DEBUG) {
-                    if (out.cmats && myq < Q) out.cmats[((myq * 3 + t) * 16 + r) * 16 + j] = v;
-                }
-            }
-            if (t == 0) {                                        // resolve_quartets.py:226 cmats[0].sum()
-#pragma unroll
-                for (int m = 1; m < 16; m <<= 1) colsum += __shfl_xor(colsum, m, WAVE);
-                my_nsnps = colsum;
-            }
-            const SvResult sv = jacobi16(a, j, lane);
-            sig[t] = sv.sigma;
-            pos[t] = sv.pos;
-            rnk[t] = sv.rank;
-            smax_all = fmax(smax_all, sv.smax);
-            if (DEBUG) {
-                if (out.svds && myq < Q) out.svds[(myq * 3 + t) * 16 + sv.pos] = sv.sigma;
-                if (out.ranks && myq < Q && j == 0) out.ranks[myq * 3 + t] = sv.rank;
-            }
-        }
-        __syncthreads();   // all reads of the staged slabs done before the next pass overwrites them
-
-        // resolve_quartets.py:246-251
-        const int minrank = min(10, min(rnk[0], min(rnk[1], rnk[2])));
-        double sc[3];
-#pragma unroll
-        for (int t = 0; t < 3; ++t) {
-            const double v = (pos[t] >= minrank) ? sig[t] * sig[t] : 0.0;
-            sc[t] = sqrt(group_sum(v));
-        }
-        if (j == 0 && myq < Q) {
-            int topo = 0;
-            if (sc[1] < sc[topo]) topo = 1;
-            if (sc[2] < sc[topo]) topo = 2;
-            // gap between the two lowest scores relative to the largest singular value
-            const double lo1 = sc[topo];
-            const double lo2 = (topo == 0) ? fmin(sc[1], sc[2]) : (topo == 1) ? fmin(sc[0], sc[2]) : fmin(sc[0], sc[1]);
-            uint32_t fl = 0;
-            if ((lo2 - lo1) <= DEGENERATE_REL_GAP * smax_all) fl |= TQ_FLAG_DEGENERATE;
-            if (my_nsnps == 0) {                 // resolve_quartets.py:230-232
-                topo = 0;
-                sc[0] = sc[1] = sc[2] = 0.001;
-                fl = TQ_FLAG_ZERO_DATA;
-            }
-            const uint4 qv = reinterpret_cast<const uint4 *>(quartets)[myq];
-            const uint32_t Tu = (uint32_t)T;
-            if ((qv.x >= Tu) | (qv.y >= Tu) | (qv.z >= Tu) | (qv.w >= Tu)) fl |= TQ_FLAG_BAD_INDEX;
-            out.rstat[myq * 2 + 0] = (uint32_t)topo;
-            out.rstat[myq * 2 + 1] = my_nsnps;
-            out.rscor[myq * 3 + 0] = sc[0];
-            out.rscor[myq * 3 + 1] = sc[1];
-            out.rscor[myq * 3 + 2] = sc[2];
-            if (out.flags) out.flags[myq] = (uint8_t)fl;
-        }
-    }
-}
-
-// ====================================================================================
-// Alternative singular-value path ("HQR"): Householder bidiagonalisation + implicit-shift QR
-// on the bidiagonal -- the same algorithm class as the LAPACK routine the reference calls
-// (resolve_quartets.py:242 -> dgesdd -> dgebrd + bidiagonal QR), ~8x fewer f64 operations
-// than Jacobi.  Three kernels:
-//   tq_bidiag_kernel : 4 lanes per matrix (lane c of a quad holds columns c, c+4, c+8, c+12 as
-//                      64 f64 registers), 16 quartets per wave pass; Householder vectors are
-//                      shared inside the quad with DPP quad_perm broadcasts, row sums with two
-//                      quad_perm butterflies -- no LDS traffic after the count slabs are staged.
-//   tq_bdsqr_kernel  : 1 lane per matrix, diagonal/superdiagonal parked in LDS (lane-major, so
-//                      dynamically indexed accesses are bank-conflict free); Golub-Kahan
-//                      implicit-shift QR sweeps with deflation.
-//   tq_score_kernel  : 1 lane per quartet: sort, rank rule, minrank, tail norms, argmin, flags.
-// The Jacobi kernel above stays selectable (tq_set_option "svd_method" 0) and is the
-// cross-check for this path in the GPU tests.
-// ====================================================================================
-template <int K>
-struct IC {
-    static constexpr int value = K;
-};
-
-template <int B, int E, typename F>
-__device__ __forceinline__ void static_for(F &&f)
-{
-    if constexpr (B < E) {
-        f(IC<B>{});
-        static_for<B + 1, E>(f);
-    }
-}
-
-template <int SRC>
-__device__ __forceinline__ double quad_bcast(double v)
-{
-    constexpr int CTRL = SRC | (SRC << 2) | (SRC << 4) | (SRC << 6);
-    const int lo = dpp_mov<CTRL>(__double2loint(v));
-    const int hi = dpp_mov<CTRL>(__double2hiint(v));
-    return __hiloint2double(hi, lo);
-}
-
-__device__ __forceinline__ double quad_sum(double v)
-{
-    v += dpx<1>(v);
-    v += dpx<2>(v);
-    return v;
-}
-
-__device__ __forceinline__ double sqrt_nr(double x)     // x >= 0, full precision, sqrt(0) = 0
-{
-    const double y = rsq_nr<2>(x);
-    const double s = x * y;
-    const double r = fma(fma(-s, s, x), 0.5 * y, s);     // one more correction on the root itself
-    return x > 0.0 ? r : 0.0;
-}
-
-// de layout: f64 [3*Q][32]: d[0..15] then e[0..15] with e[0] = 0 (e[i] couples columns i-1, i)
-template <bool DEBUG>
-__global__ void __launch_bounds__(WAVE, 2)
-tq_bidiag_kernel(const uint32_t *__restrict__ cm, int64_t Q, double *__restrict__ de,
-                 uint32_t *__restrict__ nsnps_out, uint32_t *__restrict__ cmats_dbg)
-{
-    constexpr int QP = 16;                       // quartets per wave pass (one per quad)
-    __shared__ uint32_t lds[QP * 256];
-    const int lane = threadIdx.x;
-    const int quad = lane >> 2;
-    const int c = lane & 3;
-
-    const int64_t npass = (Q + QP - 1) / QP;
-    for (int64_t wg = blockIdx.x; wg < npass; wg += gridDim.x) {
-        const int64_t q0 = wg * QP;
-        {
-            const uint4 *src = reinterpret_cast<const uint4 *>(cm + q0 * 256);
-            uint4 *dst = reinterpret_cast<uint4 *>(lds);
-#pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                const int idx = lane + WAVE * k;               // 1024 uint4 = 16 quartets x 64
-                const bool ok = (q0 + (idx >> 6)) < Q;
-                dst[idx] = ok ? src[idx] : make_uint4(0, 0, 0, 0);
-            }
-        }
-        __syncthreads();
-        const int64_t myq = q0 + quad;
-        const uint32_t *cmq = lds + 256 * quad;
-        // resolve_quartets.py:226: number of counted sites = sum of the count tensor
-        {
-            uint32_t s = 0;
-#pragma unroll
-            for (int k = 0; k < 64; ++k) s += cmq[4 * k + c];
-            s += __shfl_xor(s, 1, WAVE);
-            s += __shfl_xor(s, 2, WAVE);
-            if (c == 0 && myq < Q) nsnps_out[myq] = s;
-        }
-#pragma unroll 1
-        for (int t = 0; t < 3; ++t) {
-            double a[4][16];                                    // a[s][r] = M_t[r][4s + c]
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const uint32_t v = cmq[flat_bin(t, r, 4 * s + c)];
-                    a[s][r] = (double)v;
-                    if (DEBUG) {
-                        if (cmats_dbg && myq < Q) cmats_dbg[((myq * 3 + t) * 16 + r) * 16 + 4 * s + c] = v;
-                    }
-                }
-            }
-            // d[K] / e[K] are stored as soon as they are known (keeping 32 more f64 live would cost
-            // the kernel its second wave per SIMD)
-            double *dout = de + (myq * 3 + t) * 32;
-            const bool writer = (c == 0) && (myq < Q);
-            if (writer) dout[16] = 0.0;
-            static_for<0, 16>([&](auto kc) {
-                constexpr int K = decltype(kc)::value;
-                // ---- left reflector: zero column K below the diagonal ----
-                {
-                    constexpr int so = K >> 2, co = K & 3;
-                    double v[16];
-#pragma unroll
-                    for (int r = K; r < 16; ++r) v[r] = quad_bcast<co>(a[so][r]);
-                    double n2 = 0.0;
-#pragma unroll
-                    for (int r = K; r < 16; ++r) n2 = fma(v[r], v[r], n2);
-                    const double nrm = sqrt_nr(n2);
-                    const double x0 = v[K];
-                    const double alpha = (x0 < 0.0) ? nrm : -nrm;
-                    v[K] = x0 - alpha;
-                    const double den = fma(-alpha, x0, n2);      // = |v|^2 / 2 > 0 unless the column is zero
-                    const double beta = n2 > 0.0 ? rcp_nr<2>(den) : 0.0;
-                    if (writer) dout[K] = alpha;
-#pragma unroll
-                    for (int s = so; s < 4; ++s) {
-                        double w = 0.0;
-#pragma unroll
-                        for (int r = K; r < 16; ++r) w = fma(v[r], a[s][r], w);
-                        w *= beta;
-                        if (s == so) w = (c > co) ? w : 0.0;     // columns <= K of this slot are finished
-#pragma unroll
-                        for (int r = K; r < 16; ++r) a[s][r] = fma(-w, v[r], a[s][r]);
-                    }
-                }
-                // ---- right reflector: zero row K right of the superdiagonal ----
-                if constexpr (K <= 13) {
-                    constexpr int K1 = K + 1, s1 = K1 >> 2, c1 = K1 & 3, sb = K1 >> 2;
-                    double y[4];
-                    double p = 0.0;
-#pragma unroll
-                    for (int s = sb; s < 4; ++s) {
-                        y[s] = (4 * s + c > K) ? a[s][K] : 0.0;
-                        p = fma(y[s], y[s], p);
-                    }
-                    const double n2 = quad_sum(p);
-                    const double x0 = quad_bcast<c1>(y[s1]);
-                    const double nrm = sqrt_nr(n2);
-                    const double alpha = (x0 < 0.0) ? nrm : -nrm;
-                    const double den = fma(-alpha, x0, n2);
-                    const double beta = n2 > 0.0 ? rcp_nr<2>(den) : 0.0;
-                    if (c == c1) y[s1] = x0 - alpha;
-                    if (writer) dout[16 + K1] = alpha;
-#pragma unroll
-                    for (int i = K1; i < 16; ++i) {
-                        double q = 0.0;
-#pragma unroll
-                        for (int s = sb; s < 4; ++s) q = fma(y[s], a[s][i], q);
-                        const double tt = beta * quad_sum(q);
-#pragma unroll
-                        for (int s = sb; s < 4; ++s) a[s][i] = fma(-tt, y[s], a[s][i]);
-                    }
-                } else if constexpr (K == 14) {
-                    const double e15 = quad_bcast<3>(a[3][14]);  // column 15 lives in slot 3 of lane 3
-                    if (writer) dout[31] = e15;
-                }
-            });
-        }
-        __syncthreads();
-    }
-}
-
-// Golub-Kahan implicit-shift QR on one 16x16 bidiagonal per lane (Golub & Reinsch 1970, the
-// diagonalisation half of their SVD procedure, singular values only).  w = diagonal, e =
-// superdiagonal (e[0] unused), both parked lane-major in LDS.  sv out: f64 [nmat][16], unsorted, >= 0.
-#define W_(i) wl[(i) * WAVE]
-#define E_(i) el[(i) * WAVE]
-__device__ __forceinline__ double hypot_nr(double a, double b) { return sqrt_nr(fma(a, a, b * b)); }
-
-__global__ void __launch_bounds__(WAVE)
-tq_bdsqr_kernel(const double *__restrict__ de, int64_t nmat, double *__restrict__ sv)
-{
-    __shared__ double lds[32 * WAVE];
-    const int lane = threadIdx.x;
-    double *wl = lds + lane;
-    double *el = lds + 16 * WAVE + lane;
-    const int64_t npass = (nmat + WAVE - 1) / WAVE;
-    for (int64_t wg = blockIdx.x; wg < npass; wg += gridDim.x) {
-        const int64_t m = wg * WAVE + lane;
-        const bool live = m < nmat;
-        double anorm = 0.0;
-        double dv[16], ev[16];
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            dv[i] = live ? de[m * 32 + i] : 0.0;
-            ev[i] = live ? de[m * 32 + 16 + i] : 0.0;
-            W_(i) = dv[i];
-            E_(i) = ev[i];
-            anorm = fmax(anorm, fabs(dv[i]) + fabs(ev[i]));
-        }
-        // negligible(x): |x| + anorm == anorm, i.e. |x| <= ~eps/2 * anorm
-        const double tiny = anorm * (0.5 * F64_EPS);
-        // bit i of negE / negW: e[i] / w[i] is negligible.  Kept in registers and updated on every
-        // store, so the split search is a few bit operations instead of a dependent chain of LDS reads.
-        uint32_t negE = 0, negW = 0;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            negE |= (uint32_t)(fabs(ev[i]) <= tiny) << i;
-            negW |= (uint32_t)(fabs(dv[i]) <= tiny) << i;
-        }
-#define SET_E(i, v) do { const double v_ = (v); E_(i) = v_; negE = (negE & ~(1u << (i))) | ((uint32_t)(fabs(v_) <= tiny) << (i)); } while (0)
-#define SET_W(i, v) do { const double v_ = (v); W_(i) = v_; negW = (negW & ~(1u << (i))) | ((uint32_t)(fabs(v_) <= tiny) << (i)); } while (0)
-        // Every lane walks its own deflation index k: a lane whose current singular value has
-        // converged moves on at once instead of waiting for the slowest lane of the wave at that k.
-        int k = 15, its = 0;
-        while (k >= 0) {
-            // split point l = largest l <= k with e[l] negligible (or l == 0), unless a negligible
-            // w[l-1] is met first (then e[l] has to be chased out of the block: "cancel")
-            const uint32_t stopE = negE | 1u, stopW = negW << 1;
-            const uint32_t stops = (stopE | stopW) & ((2u << k) - 1u);
-            const int l = 31 - __builtin_clz(stops);
-            const bool cancel = ((stopE >> l) & 1u) == 0;
-            if (cancel) {
-                double cc = 0.0, ss = 1.0;
-                for (int i = l; i <= k; ++i) {
-                    const double ei = E_(i);
-                    const double f = ss * ei;
-                    SET_E(i, cc * ei);
-                    if (fabs(f) <= tiny) break;
-                    const double g = W_(i);
-                    const double h = hypot_nr(f, g);
-                    SET_W(i, h);
-                    const double hi = rcp_nr<2>(h);
-                    cc = g * hi;
-                    ss = -f * hi;
-                }
-            }
-            double z = W_(k);
-            if (l == k || its >= 60) {          // converged (or iteration cap: keep what we have)
-                W_(k) = fabs(z);
-                --k;
-                its = 0;
-                continue;
-            }
-            ++its;
-            // shift from the bottom 2x2 minor
-            double x = W_(l);
-            const int nm = k - 1;
-            double y = W_(nm);
-            double g = E_(nm);
-            double h = E_(k);
-            double f = ((y - z) * (y + z) + (g - h) * (g + h)) * rcp_nr<2>(2.0 * h * y);
-            g = hypot_nr(f, 1.0);
-            f = ((x - z) * (x + z) + h * (y * rcp_nr<2>(f + copysign(g, f)) - h)) * rcp_nr<2>(x);
-            double cc = 1.0, ss = 1.0;
-            // one QR sweep over the block [l,k]; the LDS reads of the next step are issued
-            // before the current step's arithmetic, and each hypot shares one rsq with the
-            // reciprocal its rotation needs
-            double gn = E_(l + 1), yn = W_(l + 1);
-            for (int jj = l; jj <= nm; ++jj) {
-                g = gn;
-                y = yn;
-                const int i2 = min(jj + 2, 15);
-                gn = E_(i2);
-                yn = W_(i2);
-                h = ss * g;
-                g = cc * g;
-                double zz = fma(f, f, h * h);
-                double rz = zz > 0.0 ? rsq_nr<2>(zz) : 0.0;
-                SET_E(jj, zz * rz);
-                cc = f * rz;
-                ss = h * rz;
-                f = fma(x, cc, g * ss);
-                g = fma(g, cc, -(x * ss));
-                h = y * ss;
-                y *= cc;
-                zz = fma(f, f, h * h);
-                rz = zz > 0.0 ? rsq_nr<2>(zz) : 0.0;
-                SET_W(jj, zz * rz);
-                if (zz > 0.0) {
-                    cc = f * rz;
-                    ss = h * rz;
-                }
-                f = fma(cc, g, ss * y);
-                x = fma(cc, y, -(ss * g));
-            }
-            SET_E(l, 0.0);
-            SET_E(k, f);
-            SET_W(k, x);
-        }
-#undef SET_E
-#undef SET_W
-        if (live) {
-#pragma unroll
-            for (int i = 0; i < 16; ++i) sv[m * 16 + i] = fabs(W_(i));
-        }
-    }
-}
-#undef W_
-#undef E_
-
-// one lane per quartet: resolve_quartets.py:243-251 on the three sets of singular values
-template <bool DEBUG>
-__global__ void __launch_bounds__(256)
-tq_score_kernel(const double *__restrict__ sv, const uint32_t *__restrict__ nsnps_in,
-                const uint32_t *__restrict__ quartets, int64_t Q, int32_t T, OutPtrs out)
-{
-    const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (q >= Q) return;
-    double sc2[3][16];
-    int rnk[3];
-    double smax_all = 0.0;
-#pragma unroll
-    for (int t = 0; t < 3; ++t) {
-        double s[16];
-#pragma unroll
-        for (int i = 0; i < 16; ++i) s[i] = sv[(q * 3 + t) * 16 + i];
-        // bitonic sorting network, descending (static indices only)
-#pragma unroll
-        for (int k = 2; k <= 16; k <<= 1) {
-#pragma unroll
-            for (int jj = k >> 1; jj > 0; jj >>= 1) {
-#pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const int l = i ^ jj;
-                    if (l > i) {
-                        const bool desc = (i & k) == 0;
-                        const double lo = fmin(s[i], s[l]), hi = fmax(s[i], s[l]);
-                        s[i] = desc ? hi : lo;
-                        s[l] = desc ? lo : hi;
-                    }
-                }
-            }
-        }
-        const double thr = s[0] * 16.0 * F64_EPS;        // numpy.linalg.matrix_rank rule
-        int r = 0;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            r += s[i] > thr;
-            sc2[t][i] = s[i] * s[i];
-            if (DEBUG) {
-                if (out.svds) out.svds[(q * 3 + t) * 16 + i] = s[i];
-            }
-        }
-        rnk[t] = r;
-        smax_all = fmax(smax_all, s[0]);
-        if (DEBUG) {
-            if (out.ranks) out.ranks[q * 3 + t] = r;
-        }
-    }
-    const int minrank = min(10, min(rnk[0], min(rnk[1], rnk[2])));
-    double sc[3];
-#pragma unroll
-    for (int t = 0; t < 3; ++t) {
-        double acc = 0.0;
-#pragma unroll
-        for (int i = 15; i >= 0; --i) acc += (i >= minrank) ? sc2[t][i] : 0.0;
-        sc[t] = sqrt(acc);
-    }
-    int topo = 0;
-    if (sc[1] < sc[topo]) topo = 1;
-    if (sc[2] < sc[topo]) topo = 2;
-    const double lo1 = sc[topo];
-    const double lo2 = (topo == 0) ? fmin(sc[1], sc[2]) : (topo == 1) ? fmin(sc[0], sc[2]) : fmin(sc[0], sc[1]);
-    uint32_t fl = 0;
-    if ((lo2 - lo1) <= DEGENERATE_REL_GAP * smax_all) fl |= TQ_FLAG_DEGENERATE;
-    const uint32_t nsn = nsnps_in[q];
-    if (nsn == 0) {
-        topo = 0;
-        sc[0] = sc[1] = sc[2] = 0.001;
-        fl = TQ_FLAG_ZERO_DATA;
-    }
-    const uint4 qv = reinterpret_cast<const uint4 *>(quartets)[q];
-    const uint32_t Tu = (uint32_t)T;
-    if ((qv.x >= Tu) | (qv.y >= Tu) | (qv.z >= Tu) | (qv.w >= Tu)) fl |= TQ_FLAG_BAD_INDEX;
-    out.rstat[q * 2 + 0] = (uint32_t)topo;
-    out.rstat[q * 2 + 1] = nsn;
-    out.rscor[q * 3 + 0] = sc[0];
-    out.rscor[q * 3 + 1] = sc[1];
-    out.rscor[q * 3 + 2] = sc[2];
-    if (out.flags) out.flags[q] = (uint8_t)fl;
-}
-
-// ====================================================================================
-// Bootstrap replicate built on the device.
-// Reference: resample_tmp_database (tetrad/src/run_inference.py:99-143) = jit_resample
-// (tetrad/jit/resample.py:20-64: loci resampled with replacement, columns shuffled inside each
-// locus, locus column = ordinal of the resampled locus) + jit_resolve_ambigs
-// (tetrad/jit/resolve_ambigs.py:12-36: every IUPAC two-base code resolved to one of its two
-// bases with probability 1/2, per cell) + the ACGT -> 0..3 recode (:133-136).  Here the three
-// steps and the layout build are fused: the replicate never exists on the host and nothing is
-// written back to HDF5.  Random streams: the reference uses numba's Mersenne twister seeded from
-// the project Generator; this engine uses counter-based hashes of (seed, position).  Only the
-// distribution can match (RNG-stream parity is unpinned); the host keeps the
-// reference's draw order on the project Generator (tetrad_amd/bootstrap.py).
-// ====================================================================================
-__device__ __forceinline__ uint64_t mix64(uint64_t x)     // splitmix64 finaliser
-{
-    x += 0x9E3779B97F4A7C15ull;
-    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
-    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
-    return x ^ (x >> 31);
-}
-
-// widths[i] = spans[lidx[i]][1] - spans[lidx[i]][0]
-__global__ void tq_boot_width_kernel(const int64_t *__restrict__ spans, const int64_t *__restrict__ lidxs, int64_t n,
-                                     int64_t nloci, uint32_t *__restrict__ widths)
-{
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    int64_t l = lidxs[i];
-    if (l < 0 || l >= nloci) l = 0;
-    widths[i] = (uint32_t)(spans[2 * l + 1] - spans[2 * l]);
-}
-
-// one thread per resampled locus: Fisher-Yates shuffle of its columns (resample.py:49-50);
-// src_col[s] = source column of output site s, site_locus[s] = ordinal of its resampled locus (:58)
-__global__ void tq_boot_perm_kernel(const int64_t *__restrict__ spans, const int64_t *__restrict__ lidxs,
-                                    const uint32_t *__restrict__ offsets, int64_t n, int64_t nloci, uint64_t seed,
-                                    uint32_t *__restrict__ src_col, uint32_t *__restrict__ site_locus)
-{
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    int64_t l = lidxs[i];
-    if (l < 0 || l >= nloci) l = 0;
-    const uint32_t start = (uint32_t)spans[2 * l];
-    const uint32_t w = (uint32_t)(spans[2 * l + 1] - spans[2 * l]);
-    uint32_t *p = src_col + offsets[i];
-    uint32_t *loc = site_locus + offsets[i];
-    for (uint32_t j = 0; j < w; ++j) {
-        p[j] = start + j;
-        loc[j] = (uint32_t)i;
-    }
-    uint64_t state = mix64(seed ^ ((uint64_t)i * 0xD1342543DE82EF95ull));
-    for (uint32_t j = w; j > 1; --j) {
-        state = mix64(state);
-        // unbiased enough for j << 2^32: multiply-high of a 32-bit draw
-        const uint32_t r = (uint32_t)(((state >> 32) * (uint64_t)j) >> 32);
-        const uint32_t tmp = p[j - 1];
-        p[j - 1] = p[r];
-        p[r] = tmp;
-    }
-}
-
-// one thread per 32-site word of one taxon row: gather + ambiguity resolution + recode + layout
-__global__ void tq_boot_build_kernel(const uint8_t *__restrict__ seqarr, int64_t S0,
-                                     const uint32_t *__restrict__ src_col, const uint32_t *__restrict__ site_locus,
-                                     int64_t S, int64_t Sp, int64_t W, int32_t T, uint64_t seed,
-                                     uint8_t *__restrict__ rows, uint4 *__restrict__ planes)
-{
-    int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid >= (int64_t)T * W) return;
-    const int64_t t = gid / W, w = gid - t * W;
-    uint8_t *dst = rows + t * Sp;
-    uint32_t mm = 0, b0 = 0, b1 = 0, rb = 0;
-    for (int i = 0; i < 32; ++i) {
-        const int64_t s = w * 32 + i;
-        uint8_t code = 0;
-        bool missing = true;
-        if (s < S) {
-            uint8_t v = seqarr[t * S0 + src_col[s]];
-            // IUPAC two-base codes (utils.py:14-21): R->G/A K->G/T S->G/C Y->T/C W->T/A M->C/A
-            const bool coin = (mix64(seed ^ ((uint64_t)t * 0x9E3779B97F4A7C15ull) ^ (uint64_t)s * 0xC2B2AE3D27D4EB4Full) >> 63) != 0;
-            switch (v) {
-            case 82: v = coin ? 71 : 65; break;
-            case 75: v = coin ? 71 : 84; break;
-            case 83: v = coin ? 71 : 67; break;
-            case 89: v = coin ? 84 : 67; break;
-            case 87: v = coin ? 84 : 65; break;
-            case 77: v = coin ? 67 : 65; break;
-            default: break;
-            }
-            // run_inference.py:133-136: A,C,G,T -> 0,1,2,3 ; everything else stays a byte > 3 (missing)
-            if (v == 65) { code = 0; missing = false; }
-            else if (v == 67) { code = 1; missing = false; }
-            else if (v == 71) { code = 2; missing = false; }
-            else if (v == 84) { code = 3; missing = false; }
-            else if (v <= 3) { code = v; missing = false; }       // already recoded input
-            const bool beg = (s == 0) || (site_locus[s] != site_locus[s - 1]);
-            rb |= (uint32_t)beg << i;
-        }
-        dst[row_offset(s)] = code;
-        mm |= (uint32_t)missing << i;
-        b0 |= (uint32_t)(code & 1) << i;
-        b1 |= (uint32_t)((code >> 1) & 1) << i;
-    }
-    planes[t * W + w] = make_uint4(mm, b0, b1, rb);
-}
-
-// replicate currently on the device -> the reference's tmparr (0..3, 78) / tmpmap layout
-__global__ void tq_export_kernel(const uint8_t *__restrict__ rows, const uint4 *__restrict__ planes, int64_t S,
-                                 int64_t Sp, int64_t W, int32_t T, uint8_t *__restrict__ tmparr,
-                                 uint32_t *__restrict__ tmpmap)
-{
-    int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid >= (int64_t)T * S) return;
-    const int64_t t = gid / S, s = gid - t * S;
-    const uint32_t miss = planes[t * W + (s >> 5)].x;
-    tmparr[gid] = ((miss >> (s & 31)) & 1u) ? (uint8_t)78 : rows[t * Sp + row_offset(s)];
-    if (t == 0) tmpmap[2 * s + 1] = (uint32_t)s;
-}
-
-// locus ordinals from the run-begin bits (inclusive prefix count - 1), one thread per 32-site word
-__global__ void tq_export_runcount_kernel(const uint4 *__restrict__ planes, int64_t W, uint32_t *__restrict__ cnt)
-{
-    int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (w < W) cnt[w] = (uint32_t)__popc(planes[w].w);
-}
-
-__global__ void tq_export_locus_kernel(const uint4 *__restrict__ planes, const uint32_t *__restrict__ base, int64_t S,
-                                       int64_t W, uint32_t *__restrict__ tmpmap)
-{
-    int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (w >= W) return;
-    const uint32_t rb = planes[w].w;
-    uint32_t ord = base[w];                  // run-begins before this word
-    for (int i = 0; i < 32; ++i) {
-        const int64_t s = w * 32 + i;
-        if (s >= S) break;
-        ord += (rb >> i) & 1u;
-        tmpmap[2 * s] = ord - 1u;
-    }
-}
+#include "common.hpp"
+#include "prepare.hpp"
+#include "scan.hpp"
+#include "jacobi.hpp"
+#include "hqr.hpp"
+#include "bootstrap.hpp"
 
 }  // namespace
 
@@ -2306,3 +966,4 @@ int tq_device_info(tq_ctx *ctx, int32_t *num_cu, int32_t *waves_per_cu, int64_t 
 }
 
 }  // extern "C"
+

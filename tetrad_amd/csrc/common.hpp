@@ -15,6 +15,7 @@ constexpr double DEGENERATE_REL_GAP = 1e-9;
 
 struct DevData {
     const uint8_t *rows;
+    const uint8_t *nib;     // [T][Sp/2] two base codes per byte (see nib_offset)
     const uint4 *planes;
     int64_t pitch;      // bytes per row (Sp)
     int64_t W;          // plane records per row (Sp/32)
@@ -30,6 +31,14 @@ __host__ __device__ __forceinline__ int64_t row_offset(int64_t s)
     const int64_t tile = s >> 11, r = s & 2047, lane = r >> 5, k = r & 31;
     return (tile << 11) + ((k >> 4) << 10) + (lane << 4) + (k & 15);
 }
+
+// Nibble-packed copy of the rows, read by the cooperative scan kernel for a wave's own rows c and d
+// (half the bytes through the L2 -> CU path, which is what bounds that kernel).  Eight consecutive
+// sites share four bytes: byte k of a group holds site k in its low nibble and site k+4 in its high
+// nibble, so `w & 0x0F0F0F0F` and `(w >> 4) & 0x0F0F0F0F` are the code bytes of sites 0-3 and 4-7 in
+// site order.  A lane's 32 sites are 16 contiguous bytes; a 2048-site step is 1 KiB per row.
+__host__ __device__ __forceinline__ int64_t nib_offset(int64_t s) { return ((s >> 3) << 2) + (s & 3); }
+__host__ __device__ __forceinline__ int nib_shift(int64_t s) { return (int)((s >> 2) & 1) * 4; }
 
 struct OutPtrs {
     uint32_t *rstat;    // [Q,2]

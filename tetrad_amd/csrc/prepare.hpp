@@ -7,7 +7,7 @@
 // ------------------------------------------------------------------------------------
 __global__ void tq_prepare_rows(const uint8_t *__restrict__ raw, const uint32_t *__restrict__ locus,
                                 int64_t S, int64_t Sp, int64_t W, int32_t T, uint8_t *__restrict__ rows,
-                                uint4 *__restrict__ planes)
+                                uint8_t *__restrict__ nib, uint4 *__restrict__ planes)
 {
     int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= (int64_t)T * W) return;
@@ -15,12 +15,14 @@ __global__ void tq_prepare_rows(const uint8_t *__restrict__ raw, const uint32_t 
     const uint8_t *src = raw + t * S + w * 32;
     uint8_t *dst = rows + t * Sp;
     uint32_t mm = 0, b0 = 0, b1 = 0, rb = 0;
+    uint32_t nw[4] = {0, 0, 0, 0};                 // this word's 32 sites = 16 nibble bytes
     for (int i = 0; i < 32; ++i) {
         int64_t s = w * 32 + i;
         uint8_t v = (s < S) ? src[i] : (uint8_t)0xFF;
         bool missing = v > 3;
         uint8_t code = missing ? (uint8_t)0 : v;
         dst[row_offset(s)] = code;
+        nw[i >> 3] |= (uint32_t)code << (8 * (i & 3) + 4 * ((i >> 2) & 1));
         mm |= (uint32_t)missing << i;
         b0 |= (uint32_t)(code & 1) << i;
         b1 |= (uint32_t)((code >> 1) & 1) << i;
@@ -30,6 +32,7 @@ __global__ void tq_prepare_rows(const uint8_t *__restrict__ raw, const uint32_t 
         }
     }
     planes[t * W + w] = make_uint4(mm, b0, b1, rb);
+    reinterpret_cast<uint4 *>(nib + t * (Sp / 2))[w] = make_uint4(nw[0], nw[1], nw[2], nw[3]);
 }
 
 // ------------------------------------------------------------------------------------

@@ -39,14 +39,15 @@ __device__ __forceinline__ void load_tile(TileRegs &r, const DevData &d, const u
 //                    t(i) = U(i) | (P(i) & t(i-1)), P = ~runbegin, seen(i) = P(i) & t(i-1),
 //                    which is the carry recurrence of the addition (U|P) + U.
 template <bool SUB>
-__device__ __forceinline__ uint32_t count_mask(const TileRegs &r, int lane, uint32_t &tile_carry)
+__device__ __forceinline__ uint32_t count_mask(const uint4 &pa, const uint4 &pb, const uint4 &pc, const uint4 &pd,
+                                               int lane, uint32_t &tile_carry)
 {
-    const uint32_t M = r.pa.x | r.pb.x | r.pc.x | r.pd.x;
-    const uint32_t V = (r.pa.y ^ r.pb.y) | (r.pa.z ^ r.pb.z) | (r.pa.y ^ r.pc.y) | (r.pa.z ^ r.pc.z) |
-                       (r.pa.y ^ r.pd.y) | (r.pa.z ^ r.pd.z);
+    const uint32_t M = pa.x | pb.x | pc.x | pd.x;
+    const uint32_t V = (pa.y ^ pb.y) | (pa.z ^ pb.z) | (pa.y ^ pc.y) | (pa.z ^ pc.z) |
+                       (pa.y ^ pd.y) | (pa.z ^ pd.z);
     const uint32_t U = V & ~M;
     if (!SUB) return U;
-    const uint32_t B = r.pa.w;
+    const uint32_t B = pa.w;
     const uint32_t P = ~B;
     const uint32_t X = U | P;
     const uint32_t sum = X + U;
@@ -68,68 +69,41 @@ __device__ __forceinline__ uint32_t count_mask(const TileRegs &r, int lane, uint
     return U & ~seen;
 }
 
-// four sites (one dword of each row): EXEC-masked histogram increments for the counted ones
-template <int NREP>
-__device__ __forceinline__ void hist_dword(uint32_t a, uint32_t b, uint32_t c, uint32_t d, uint32_t C, int site0,
-                                           uint32_t *hrep)
-{
-    // base codes are 0..3, so the per-byte pattern (a<<6|b<<4|c<<2|d) never crosses a byte
-    const uint32_t pat = (((((a << 2) + b) << 2) + c) << 2) + d;     // fields never overlap: + == |, one v_lshl_add each
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        if (C & (1u << (site0 + k)))
-            __hip_atomic_fetch_add(&hrep[((pat >> (8 * k)) & 0xFFu) * NREP], 1u, __ATOMIC_RELAXED,
-                                   __HIP_MEMORY_SCOPE_WORKGROUP);
-    }
-}
-
 // METHOD 0: one EXEC-masked ds_add per site slot (32 per step, whatever the density).
 // METHOD 1: the lane parks its 32 pattern bytes in LDS and walks the set bits of C: the number of
 //           ds_add per step is the largest per-lane count in the wave (~10 of 32 in subsample
 //           mode, where at most one site per locus run is counted).
+// METHOD 2 / 3: timing diagnostics (no histogram / no per-step barrier); results are wrong.
 constexpr int PAT_STRIDE = 36;   // bytes per lane in the pattern park (9 dwords: conflict-free b32 stores)
 
-template <int NREP, bool SUB, int METHOD>
-__device__ __forceinline__ void process_tile(const TileRegs &t, int lane, uint32_t &tile_carry, uint32_t *hrep,
-                                             uint8_t *park)
+// pat[j] holds the 8-bit patterns (a<<6|b<<4|c<<2|d) of sites 4j..4j+3 of this lane, one per byte
+template <int NREP, int METHOD>
+__device__ __forceinline__ void hist_patterns(const uint32_t (&pat)[8], uint32_t C, uint32_t *hrep, uint8_t *park)
 {
-    const uint32_t C = count_mask<SUB>(t, lane, tile_carry);
-    if (METHOD == 2) {          // timing diagnostic: everything but the histogram (results are wrong)
-#define TQ_PAT(a, b, c, d) (((((((a) << 2) + (b)) << 2) + (c)) << 2) + (d))
+    if (METHOD == 2) {
         uint32_t acc = C;
-        acc ^= TQ_PAT(t.a0.x, t.b0.x, t.c0.x, t.d0.x) ^ TQ_PAT(t.a0.y, t.b0.y, t.c0.y, t.d0.y);
-        acc ^= TQ_PAT(t.a0.z, t.b0.z, t.c0.z, t.d0.z) ^ TQ_PAT(t.a0.w, t.b0.w, t.c0.w, t.d0.w);
-        acc ^= TQ_PAT(t.a1.x, t.b1.x, t.c1.x, t.d1.x) ^ TQ_PAT(t.a1.y, t.b1.y, t.c1.y, t.d1.y);
-        acc ^= TQ_PAT(t.a1.z, t.b1.z, t.c1.z, t.d1.z) ^ TQ_PAT(t.a1.w, t.b1.w, t.c1.w, t.d1.w);
-#undef TQ_PAT
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc ^= pat[j];
         asm volatile("" ::"v"(acc));
     } else if (METHOD == 0) {
-        hist_dword<NREP>(t.a0.x, t.b0.x, t.c0.x, t.d0.x, C, 0, hrep);
-        hist_dword<NREP>(t.a0.y, t.b0.y, t.c0.y, t.d0.y, C, 4, hrep);
-        hist_dword<NREP>(t.a0.z, t.b0.z, t.c0.z, t.d0.z, C, 8, hrep);
-        hist_dword<NREP>(t.a0.w, t.b0.w, t.c0.w, t.d0.w, C, 12, hrep);
-        hist_dword<NREP>(t.a1.x, t.b1.x, t.c1.x, t.d1.x, C, 16, hrep);
-        hist_dword<NREP>(t.a1.y, t.b1.y, t.c1.y, t.d1.y, C, 20, hrep);
-        hist_dword<NREP>(t.a1.z, t.b1.z, t.c1.z, t.d1.z, C, 24, hrep);
-        hist_dword<NREP>(t.a1.w, t.b1.w, t.c1.w, t.d1.w, C, 28, hrep);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (C & (1u << (4 * j + k)))
+                    __hip_atomic_fetch_add(&hrep[((pat[j] >> (8 * k)) & 0xFFu) * NREP], 1u, __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        }
     } else {
         uint32_t *pw = reinterpret_cast<uint32_t *>(park);
-#define TQ_PAT(a, b, c, d) (((((((a) << 2) + (b)) << 2) + (c)) << 2) + (d))
-        pw[0] = TQ_PAT(t.a0.x, t.b0.x, t.c0.x, t.d0.x);
-        pw[1] = TQ_PAT(t.a0.y, t.b0.y, t.c0.y, t.d0.y);
-        pw[2] = TQ_PAT(t.a0.z, t.b0.z, t.c0.z, t.d0.z);
-        pw[3] = TQ_PAT(t.a0.w, t.b0.w, t.c0.w, t.d0.w);
-        pw[4] = TQ_PAT(t.a1.x, t.b1.x, t.c1.x, t.d1.x);
-        pw[5] = TQ_PAT(t.a1.y, t.b1.y, t.c1.y, t.d1.y);
-        pw[6] = TQ_PAT(t.a1.z, t.b1.z, t.c1.z, t.d1.z);
-        pw[7] = TQ_PAT(t.a1.w, t.b1.w, t.c1.w, t.d1.w);
-#undef TQ_PAT
+#pragma unroll
+        for (int j = 0; j < 8; ++j) pw[j] = pat[j];
         // set-bit walk, software pipelined: the pattern byte of the NEXT counted site is requested
-        // before the histogram increment of the current one, so the LDS read latency of one step
-        // hides behind the previous step instead of stalling every iteration
+        // before the histogram increment of the current one (two alternating registers: a copy
+        // would wait for the read it copies)
         uint32_t c = C;
         if (c) {
-            // two alternating registers instead of a copy: a copy would wait for the read it copies
             uint32_t b0 = park[__builtin_ctz(c)], b1 = 0;
             c &= c - 1;
             for (;;) {
@@ -150,6 +124,29 @@ __device__ __forceinline__ void process_tile(const TileRegs &t, int lane, uint32
             }
         }
     }
+}
+
+// base codes are 0..3, so (a<<6|b<<4|c<<2|d) never crosses a byte and + == | (one v_lshl_add per field)
+__device__ __forceinline__ uint32_t pat4(uint32_t a, uint32_t b, uint32_t c, uint32_t d)
+{
+    return ((((((a << 2) + b) << 2) + c) << 2) + d);
+}
+
+template <int NREP, bool SUB, int METHOD>
+__device__ __forceinline__ void process_tile(const TileRegs &t, int lane, uint32_t &tile_carry, uint32_t *hrep,
+                                             uint8_t *park)
+{
+    const uint32_t C = count_mask<SUB>(t.pa, t.pb, t.pc, t.pd, lane, tile_carry);
+    uint32_t pat[8];
+    pat[0] = pat4(t.a0.x, t.b0.x, t.c0.x, t.d0.x);
+    pat[1] = pat4(t.a0.y, t.b0.y, t.c0.y, t.d0.y);
+    pat[2] = pat4(t.a0.z, t.b0.z, t.c0.z, t.d0.z);
+    pat[3] = pat4(t.a0.w, t.b0.w, t.c0.w, t.d0.w);
+    pat[4] = pat4(t.a1.x, t.b1.x, t.c1.x, t.d1.x);
+    pat[5] = pat4(t.a1.y, t.b1.y, t.c1.y, t.d1.y);
+    pat[6] = pat4(t.a1.z, t.b1.z, t.c1.z, t.d1.z);
+    pat[7] = pat4(t.a1.w, t.b1.w, t.c1.w, t.d1.w);
+    hist_patterns<NREP, METHOD>(pat, C, hrep, park);
 }
 
 // Double-buffered scan: the loads of step t+1 are issued before step t is processed; the
@@ -231,15 +228,18 @@ tq_scan_kernel(DevData d, const uint32_t *__restrict__ quartets, const uint32_t 
 // ------------------------------------------------------------------------------------
 // kernel 1, workgroup-cooperative form: NW wavefronts = NW neighbours of the (a,b)-sorted order.
 // Quartets that share their first two taxa share two of their four rows, so the workgroup fetches
-// the rows (and plane records) of taxa a and b ONCE per 2048-site step into LDS (all NW*64 threads
-// cooperate: 384 x 16 B), double-buffered with one barrier per step; every wave still streams its
-// own rows c and d straight to registers.  Cache traffic per quartet falls from 12 KiB to
-// 6 + 6/NW KiB per step -- the scan kernel is L2 / Infinity-Cache bandwidth bound.  A wave whose
-// (a,b) differs from the leader's (group boundary in the sorted order) reads its own a and b
-// from global memory instead; it still takes part in the loads and barriers.
+// the rows and plane records of taxa a and b ONCE per 2048-site step (waves 0-1 combine the code
+// bytes of a and b into the pattern partial (a<<6|b<<4) -- 2 KiB per step -- waves 2-3 copy the two
+// plane records), double-buffered in LDS with one barrier per step.  Every wave still streams its
+// own rows c and d straight to registers, from the NIBBLE-packed copy (1 KiB per row per step) plus
+// one 16-byte plane record each.  The kernel is bound by the L2 -> CU delivery rate (~17-18 TB/s
+// chip-wide for L2-resident data); bytes through that path per quartet-step fall from 12 KiB
+// (independent waves, byte rows) to 4 + 6/NW KiB.  A wave whose (a,b) differs from the leader's
+// (group boundary in the sorted order) builds its own partial from global memory instead; it
+// still takes part in the loads and barriers.
 // ------------------------------------------------------------------------------------
 struct OwnRegs {
-    uint4 c0, c1, d0, d1, pc, pd;
+    uint4 c, d, pc, pd;      // nibble-packed codes of rows c and d (32 sites each), their plane records
 };
 
 // 16-byte load at a wave-uniform base + 32-bit per-lane byte offset (lets the compiler use the
@@ -250,32 +250,39 @@ __device__ __forceinline__ uint4 ld16(const uint8_t *base, uint32_t off)
     return *reinterpret_cast<const uint4 *>(base + off);
 }
 
-// per-lane byte offsets of a wave's own rows c, d (rows array) and their plane records
+// per-lane byte offsets of a wave's own rows c, d (nibble array) and their plane records
 struct OwnOff {
     uint32_t c, d, pc, pd;
 };
 
-__device__ __forceinline__ void load_own(OwnRegs &r, const uint8_t *rows, const uint8_t *planes, const OwnOff &o,
+__device__ __forceinline__ void load_own(OwnRegs &r, const uint8_t *nib, const uint8_t *planes, const OwnOff &o,
                                          int tile)
 {
-    const uint32_t tb = (uint32_t)tile * TILE, tp = (uint32_t)tile * (WAVE * 16);
-    r.c0 = ld16(rows, o.c + tb);
-    r.c1 = ld16(rows, o.c + tb + 1024);
-    r.d0 = ld16(rows, o.d + tb);
-    r.d1 = ld16(rows, o.d + tb + 1024);
+    const uint32_t tn = (uint32_t)tile * (TILE / 2), tp = (uint32_t)tile * (WAVE * 16);
+    r.c = ld16(nib, o.c + tn);
+    r.d = ld16(nib, o.d + tn);
     r.pc = ld16(planes, o.pc + tp);
     r.pd = ld16(planes, o.pd + tp);
 }
 
-constexpr int SHARED_PIECES = 384;   // uint4 per step: row a 128, row b 128, planes a 64, planes b 64
+// (c<<2|d) code bytes of 8 sites from one nibble dword of each row: lo = sites 0-3, hi = sites 4-7
+__device__ __forceinline__ void cd_pair(uint32_t cw, uint32_t dw, uint32_t &lo, uint32_t &hi)
+{
+    lo = ((cw & 0x0F0F0F0Fu) << 2) + (dw & 0x0F0F0F0Fu);
+    hi = (((cw >> 4) & 0x0F0F0F0Fu) << 2) + ((dw >> 4) & 0x0F0F0F0Fu);
+}
+
+// LDS image of the shared part of one step: abp = pattern partial ((a<<2)+b)<<4 as 2 x 64 uint4
+// panels (sites 0-15 / 16-31 of every lane), then the plane records of a and of b (64 uint4 each)
+constexpr int SHARED_SLOTS = 256;
 
 template <bool SUB, int METHOD, int NW>
 __global__ void __launch_bounds__(NW *WAVE)
 tq_scan_wg_kernel(DevData d, const uint32_t *__restrict__ quartets, const uint32_t *__restrict__ order, int64_t Q,
                   uint32_t *__restrict__ cm)
 {
-    static_assert(NW * WAVE >= SHARED_PIECES, "one cooperative piece per thread");
-    __shared__ uint4 shared_ab[2][SHARED_PIECES];
+    static_assert(NW >= 4, "waves 0-3 are the cooperative loaders");
+    __shared__ uint4 shared_ab[2][SHARED_SLOTS];
     __shared__ uint32_t hist_all[NW][256];
     __shared__ uint32_t park_all[NW][WAVE * PAT_STRIDE / 4];
     const int tid = threadIdx.x;
@@ -288,13 +295,12 @@ tq_scan_wg_kernel(DevData d, const uint32_t *__restrict__ quartets, const uint32
     const int last = d.ntiles - 1;
     const int64_t nblk = (Q + NW - 1) / NW;
     const uint8_t *rows = d.rows;
+    const uint8_t *nib = d.nib;
     const uint8_t *planes = reinterpret_cast<const uint8_t *>(d.planes);
-    const uint32_t pitch = (uint32_t)d.pitch, wpitch = (uint32_t)d.W * 16u;
-    // this thread's cooperative piece: waves 0-3 fetch row bytes of a / b, waves 4-5 plane records
-    const uint8_t *sh_base = tid < 256 ? rows : planes;                       // wave-uniform
-    const uint32_t sh_step = tid < 256 ? (uint32_t)TILE : (uint32_t)(WAVE * 16);
-    const uint32_t sh_lane = tid < 256 ? (uint32_t)(tid & 127) * 16u : (uint32_t)((tid - 256) & 63) * 16u;
-    const bool sh_is_b = tid < 256 ? (tid >= 128) : (tid >= 320);
+    const uint32_t pitch = (uint32_t)d.pitch, npitch = pitch / 2, wpitch = (uint32_t)d.W * 16u;
+    // cooperative roles (wave-uniform): waves 0,1 = code-byte panels 0,1 of rows a and b -> abp;
+    // wave 2 = plane records of a; wave 3 = plane records of b; other waves load nothing shared
+    const bool ld_bytes = w < 2, ld_planes = (w == 2) | (w == 3);
     __syncthreads();
 
     for (int64_t blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
@@ -320,73 +326,103 @@ tq_scan_wg_kernel(DevData d, const uint32_t *__restrict__ quartets, const uint32
         const bool shares = work && leader_ok && q[0] == la && q[1] == lb;
         const uint32_t qc = work ? q[2] : 0, qd = work ? q[3] : 0;
         OwnOff oo;
-        oo.c = qc * pitch + (uint32_t)lane * 16u;
-        oo.d = qd * pitch + (uint32_t)lane * 16u;
+        oo.c = qc * npitch + (uint32_t)lane * 16u;
+        oo.d = qd * npitch + (uint32_t)lane * 16u;
         oo.pc = qc * wpitch + (uint32_t)lane * 16u;
         oo.pd = qd * wpitch + (uint32_t)lane * 16u;
-        const uint32_t sh_off = (sh_is_b ? lb : la) * (tid < 256 ? pitch : wpitch) + sh_lane;
+        // cooperative loads of this thread: two 16-byte pieces
+        //   waves 0,1: the same 16 code bytes of row a and of row b (panel w)  -> one abp piece
+        //   wave 2/3 : plane record of a / b for lane `lane`
+        const uint32_t sh0 = ld_bytes ? la * pitch + (uint32_t)w * 1024u + (uint32_t)lane * 16u
+                                      : (w == 2 ? la : lb) * wpitch + (uint32_t)lane * 16u;
+        const uint32_t sh1 = lb * pitch + (uint32_t)w * 1024u + (uint32_t)lane * 16u;
+        const uint8_t *sh_base = ld_bytes ? rows : planes;                    // wave-uniform
+        const uint32_t sh_step = ld_bytes ? (uint32_t)TILE : (uint32_t)(WAVE * 16);
+        const int slot = ld_bytes ? tid : 128 + (w - 2) * 64 + lane;          // abp panels 0-127, planes a 128-191, b 192-255
+
+        auto fetch_shared = [&](int tile, uint4 &x, uint4 &y) {
+            if (ld_bytes) {
+                x = ld16(rows, sh0 + (uint32_t)tile * sh_step);
+                y = ld16(rows, sh1 + (uint32_t)tile * sh_step);
+            } else if (ld_planes) {
+                x = ld16(sh_base, sh0 + (uint32_t)tile * sh_step);
+            }
+        };
+        auto store_shared = [&](int buf, const uint4 &x, const uint4 &y) {
+            if (ld_bytes) {
+                uint4 p;
+                p.x = (((x.x << 2) + y.x) << 4);
+                p.y = (((x.y << 2) + y.y) << 4);
+                p.z = (((x.z << 2) + y.z) << 4);
+                p.w = (((x.w << 2) + y.w) << 4);
+                shared_ab[buf][slot] = p;
+            } else if (ld_planes) {
+                shared_ab[buf][slot] = x;
+            }
+        };
 
         // prologue: step 0 into buffer 0
-        const int slot = tid;     // rows are stored in panels already (row_offset), so piece p is slot p
-        if (tid < SHARED_PIECES) shared_ab[0][slot] = ld16(sh_base, sh_off);
+        uint4 sx = make_uint4(0, 0, 0, 0), sy = sx;
+        fetch_shared(0, sx, sy);
         OwnRegs A, B;
-        load_own(A, rows, planes, oo, 0);
+        load_own(A, nib, planes, oo, 0);
+        store_shared(0, sx, sy);
         uint32_t tile_carry = 0;
         __syncthreads();
 
         auto step = [&](const OwnRegs &own, int t) {
-            TileRegs r;
+            if (!work) return;
+            uint4 ab0, ab1, pa, pb;                        // abp panels (sites 0-15, 16-31), plane records
             if (shares) {
                 const uint4 *buf = shared_ab[t & 1];
-                r.a0 = buf[lane];
-                r.a1 = buf[64 + lane];
-                r.b0 = buf[128 + lane];
-                r.b1 = buf[192 + lane];
-                r.pa = buf[256 + lane];
-                r.pb = buf[320 + lane];
-            } else if (work) {                               // group boundary: private rows a and b
-                const int64_t boff = (int64_t)t * TILE + lane * 16;
-                const uint4 *pa = reinterpret_cast<const uint4 *>(d.rows + (int64_t)q[0] * d.pitch + boff);
-                const uint4 *pb = reinterpret_cast<const uint4 *>(d.rows + (int64_t)q[1] * d.pitch + boff);
-                r.a0 = pa[0]; r.a1 = pa[64];
-                r.b0 = pb[0]; r.b1 = pb[64];
-                const int64_t woff = (int64_t)t * WAVE + lane;
-                r.pa = d.planes[(int64_t)q[0] * d.W + woff];
-                r.pb = d.planes[(int64_t)q[1] * d.W + woff];
+                ab0 = buf[lane];
+                ab1 = buf[64 + lane];
+                pa = buf[128 + lane];
+                pb = buf[192 + lane];
+            } else {                                        // group boundary: private rows a and b
+                const uint32_t o0 = q[0] * pitch + (uint32_t)t * TILE + (uint32_t)lane * 16u;
+                const uint32_t o1 = q[1] * pitch + (uint32_t)t * TILE + (uint32_t)lane * 16u;
+                const uint4 a0 = ld16(rows, o0), a1 = ld16(rows, o0 + 1024u);
+                const uint4 b0 = ld16(rows, o1), b1 = ld16(rows, o1 + 1024u);
+                ab0 = make_uint4(((a0.x << 2) + b0.x) << 4, ((a0.y << 2) + b0.y) << 4, ((a0.z << 2) + b0.z) << 4,
+                                 ((a0.w << 2) + b0.w) << 4);
+                ab1 = make_uint4(((a1.x << 2) + b1.x) << 4, ((a1.y << 2) + b1.y) << 4, ((a1.z << 2) + b1.z) << 4,
+                                 ((a1.w << 2) + b1.w) << 4);
+                pa = ld16(planes, q[0] * wpitch + (uint32_t)t * (WAVE * 16) + (uint32_t)lane * 16u);
+                pb = ld16(planes, q[1] * wpitch + (uint32_t)t * (WAVE * 16) + (uint32_t)lane * 16u);
             }
-            if (work) {
-                r.c0 = own.c0; r.c1 = own.c1;
-                r.d0 = own.d0; r.d1 = own.d1;
-                r.pc = own.pc; r.pd = own.pd;
-                process_tile<1, SUB, METHOD>(r, lane, tile_carry, hist, park);
-            }
+            const uint32_t C = count_mask<SUB>(pa, pb, own.pc, own.pd, lane, tile_carry);
+            uint32_t pat[8], lo, hi;
+            cd_pair(own.c.x, own.d.x, lo, hi); pat[0] = ab0.x + lo; pat[1] = ab0.y + hi;
+            cd_pair(own.c.y, own.d.y, lo, hi); pat[2] = ab0.z + lo; pat[3] = ab0.w + hi;
+            cd_pair(own.c.z, own.d.z, lo, hi); pat[4] = ab1.x + lo; pat[5] = ab1.y + hi;
+            cd_pair(own.c.w, own.d.w, lo, hi); pat[6] = ab1.z + lo; pat[7] = ab1.w + hi;
+            hist_patterns<1, METHOD == 3 ? 1 : METHOD>(pat, C, hist, park);
         };
 
         for (int t = 0; t < d.ntiles; t += 2) {
             // ---- even step: prefetch t+1 (own -> B, shared -> registers), process A ----
             {
                 const int tn = min(t + 1, last);
-                uint4 sh = make_uint4(0, 0, 0, 0);
-                if (tid < SHARED_PIECES) sh = ld16(sh_base, sh_off + (uint32_t)tn * sh_step);
-                load_own(B, rows, planes, oo, tn);
+                fetch_shared(tn, sx, sy);
+                load_own(B, nib, planes, oo, tn);
                 __builtin_amdgcn_sched_barrier(0);
                 step(A, t);
                 __builtin_amdgcn_sched_barrier(0);
-                if (tid < SHARED_PIECES) shared_ab[(t + 1) & 1][slot] = sh;
-                __syncthreads();
+                store_shared((t + 1) & 1, sx, sy);
+                if (METHOD != 3) __syncthreads();      // METHOD 3 = timing diagnostic without the barrier
             }
             if (t + 1 >= d.ntiles) break;
             // ---- odd step ----
             {
                 const int tn = min(t + 2, last);
-                uint4 sh = make_uint4(0, 0, 0, 0);
-                if (tid < SHARED_PIECES) sh = ld16(sh_base, sh_off + (uint32_t)tn * sh_step);
-                load_own(A, rows, planes, oo, tn);
+                fetch_shared(tn, sx, sy);
+                load_own(A, nib, planes, oo, tn);
                 __builtin_amdgcn_sched_barrier(0);
                 step(B, t + 1);
                 __builtin_amdgcn_sched_barrier(0);
-                if (tid < SHARED_PIECES) shared_ab[t & 1][slot] = sh;
-                __syncthreads();
+                store_shared(t & 1, sx, sy);
+                if (METHOD != 3) __syncthreads();
             }
         }
         // store the 256 counts of this wave's quartet and clear its histogram
@@ -402,4 +438,3 @@ tq_scan_wg_kernel(DevData d, const uint32_t *__restrict__ quartets, const uint32
         __syncthreads();
     }
 }
-

@@ -60,6 +60,7 @@ struct tq_ctx {
     // replicate data
     int64_t T = 0, S = 0, Sp = 0, W = 0;
     uint8_t *d_rows = nullptr;
+    uint8_t *d_nib = nullptr;       // [T][Sp/2] nibble-packed copy of the rows (common.hpp: nib_offset)
     uint4 *d_planes = nullptr;      // [T][W] {miss, p0, p1, runbeg}
     bool have_data = false;
     bool locus_runs_ok = false;
@@ -137,8 +138,10 @@ int fail(tq_ctx *ctx, int code, const char *fmt, ...)
 void free_data(tq_ctx *ctx)
 {
     if (ctx->d_rows) (void)hipFree(ctx->d_rows);
+    if (ctx->d_nib) (void)hipFree(ctx->d_nib);
     if (ctx->d_planes) (void)hipFree(ctx->d_planes);
     ctx->d_rows = nullptr;
+    ctx->d_nib = nullptr;
     ctx->d_planes = nullptr;
     ctx->have_data = false;
     ctx->data_capacity = 0;
@@ -223,6 +226,7 @@ DevData dev_data(const tq_ctx *ctx)
 {
     DevData d;
     d.rows = ctx->d_rows;
+    d.nib = ctx->d_nib;
     d.planes = ctx->d_planes;
     d.pitch = ctx->Sp;
     d.W = ctx->W;
@@ -286,6 +290,7 @@ int launch_scan_n(tq_ctx *ctx, const uint32_t *dq, const uint32_t *order, int64_
     if (ctx->scan_wg == 8 && Q >= 64 && (uint64_t)ctx->T * (uint64_t)ctx->Sp < 0xFFFF0000ull) {
         const int m = ctx->scan_method < 0 ? (subsample ? 1 : 0) : ctx->scan_method;
         if (m == 2) return launch_scan_wg<true, 2, 8>(ctx, dq, order, Q, stream);   // diagnostic
+        if (m == 3) return launch_scan_wg<true, 3, 8>(ctx, dq, order, Q, stream);   // diagnostic
         if (subsample)
             return m ? launch_scan_wg<true, 1, 8>(ctx, dq, order, Q, stream)
                      : launch_scan_wg<true, 0, 8>(ctx, dq, order, Q, stream);
@@ -587,6 +592,7 @@ int tq_set_data(tq_ctx *ctx, const uint8_t *tmparr, int64_t T, int64_t S, const 
     uint8_t *d_raw = nullptr;
     uint32_t *d_loc = nullptr;
     TQ_HIP(ctx, hipMalloc((void **)&ctx->d_rows, (size_t)(T * Sp)));
+    TQ_HIP(ctx, hipMalloc((void **)&ctx->d_nib, (size_t)(T * Sp / 2)));
     TQ_HIP(ctx, hipMalloc((void **)&ctx->d_planes, (size_t)(T * W) * sizeof(uint4)));
     TQ_HIP(ctx, hipMalloc((void **)&d_raw, (size_t)(T * S)));
     hipError_t e = hipMalloc((void **)&d_loc, (size_t)S * sizeof(uint32_t));
@@ -599,7 +605,7 @@ int tq_set_data(tq_ctx *ctx, const uint8_t *tmparr, int64_t T, int64_t S, const 
     if (e == hipSuccess) {
         const int64_t n = T * W;
         hipLaunchKernelGGL(tq_prepare_rows, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, d_raw, d_loc, S, Sp,
-                           W, (int32_t)T, ctx->d_rows, ctx->d_planes);
+                           W, (int32_t)T, ctx->d_rows, ctx->d_nib, ctx->d_planes);
         e = hipGetLastError();
         if (e == hipSuccess) e = hipDeviceSynchronize();
     }
@@ -795,7 +801,7 @@ int tq_set_option(tq_ctx *ctx, const char *name, int64_t value)
         return TQ_OK;
     }
     if (!strcmp(name, "scan_method")) {
-        if (value != 0 && value != 1 && value != -1 && value != 2)
+        if (value != 0 && value != 1 && value != -1 && value != 2 && value != 3)
             return fail(ctx, TQ_ERR_INVALID_ARG, "scan_method must be -1 (auto), 0, 1 (or 2: timing diagnostic)");
         ctx->scan_method = (int)value;
         return TQ_OK;
@@ -893,6 +899,7 @@ int tq_bootstrap(tq_ctx *ctx, const int64_t *lidxs, int64_t n, uint64_t seed_shu
         free_data(ctx);
         const int64_t capSp = (int64_t)align_up((size_t)(Sp + Sp / 8), TILE);   // head-room: replicate lengths vary
         TQ_HIP(ctx, hipMalloc((void **)&ctx->d_rows, (size_t)(T * capSp)));
+        TQ_HIP(ctx, hipMalloc((void **)&ctx->d_nib, (size_t)(T * capSp / 2)));
         TQ_HIP(ctx, hipMalloc((void **)&ctx->d_planes, (size_t)(T * (capSp / 32)) * sizeof(uint4)));
         ctx->data_capacity = capSp;
     }
@@ -900,7 +907,8 @@ int tq_bootstrap(tq_ctx *ctx, const int64_t *lidxs, int64_t n, uint64_t seed_shu
                        ctx->d_lidxs, offsets, n, ctx->nloci, seed_shuffle, src_col, site_locus);
     const int64_t nw = T * W;
     hipLaunchKernelGGL(tq_boot_build_kernel, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, 0, ctx->d_seqarr,
-                       ctx->src_S0, src_col, site_locus, S, Sp, W, (int32_t)T, seed_ambig, ctx->d_rows, ctx->d_planes);
+                       ctx->src_S0, src_col, site_locus, S, Sp, W, (int32_t)T, seed_ambig, ctx->d_rows, ctx->d_nib,
+                       ctx->d_planes);
     TQ_HIP(ctx, hipGetLastError());
     TQ_HIP(ctx, hipDeviceSynchronize());
     ctx->T = T;

@@ -151,6 +151,11 @@ int tq_timing_read_split(tq_ctx *ctx, double *total_ms, double *scan_ms, double 
  * 1 Householder+QR), overlap, ov_scan_wgs, ov_svd_waves, phases (timing diagnostics).           */
 int tq_set_option(tq_ctx *ctx, const char *name, int64_t value);
 
+/* Test hook: copy the scratch of the last resolve call to the host.  which = 0: count slab
+ * u32[n][256]; 1: bidiagonals f64[3n][32] (d[16], e[16]); 2: singular values f64[3n][16] (unsorted),
+ * n = quartets of the last batch.  No reference counterpart.                                   */
+int tq_debug_fetch(tq_ctx *ctx, int which, void *dst, int64_t bytes);
+
 /* Device facts used by bench.py: writes CU count, wave slots used by the resolve
  * kernel per CU and the padded row pitch in bytes.                                 */
 int tq_device_info(tq_ctx *ctx, int32_t *num_cu, int32_t *waves_per_cu, int64_t *row_pitch);

@@ -278,3 +278,42 @@ def test_pipeline_options_do_not_change_results(engine):
     finally:
         for k, v in (("overlap", 0), ("scan_wg", 8), ("order", 1), ("batch", 0), ("scan_method", -1)):
             engine.set_option(k, v)
+
+
+@pytest.mark.parametrize("T,S,seed,p,missing,sub", [
+    (30, 400, 77, 0.02, 0.35, True),      # sparse: many rank-deficient matrices, zero columns between live ones
+    (24, 250, 5, 0.01, 0.60, False),      # very sparse, full mode
+    (22, 3000, 9, 0.30, 0.00, True),      # saturated: every pattern occurs, full rank
+])
+def test_hqr_and_jacobi_agree_on_stress_data(oracle, T, S, seed, p, missing, sub):
+    """The two device SVD paths against each other on every quartet of awkward inputs, and both
+    against numpy's rank on a sample: identical ranks and nsnps, singular values within tolerance,
+    identical topology wherever neither path flags the row.  (This test found the zero-column
+    cascade in the Householder path that the golden cases did not exercise.)"""
+    from tetrad_amd import synth
+    from tetrad_amd.engine import QuartetEngine
+    tmparr, tmpmap = synth.simulate_tmparr(T, S, seed=seed, p=p, missing=missing)
+    q = synth.all_quartets(T)
+    res = {}
+    with QuartetEngine(0) as eng:
+        eng.set_data(tmparr, tmpmap)
+        for name, m in (("hqr", 1), ("jacobi", 0)):
+            eng.set_option("svd_method", m)
+            res[name] = eng.resolve(q, sub, debug=True)
+    (r1, s1, f1, d1), (r0, s0, f0, d0) = res["hqr"], res["jacobi"]
+    np.testing.assert_array_equal(r1[:, 1], r0[:, 1])
+    np.testing.assert_array_equal(d1["cmats"], d0["cmats"])
+    np.testing.assert_array_equal(d1["ranks"], d0["ranks"])
+    smax = np.maximum(d0["svds"].max(axis=(1, 2)), 1e-300)
+    assert_close(d1["svds"], d0["svds"], smax[:, None, None], "singular values HQR vs Jacobi")
+    assert_close(s1, s0, smax[:, None], "scores HQR vs Jacobi")
+    assert np.isfinite(s1).all() and np.isfinite(d1["svds"]).all()
+    ok = ((f1 | f0) & 3) == 0
+    np.testing.assert_array_equal(r1[ok, 0], r0[ok, 0])
+    # numpy.linalg.matrix_rank on a sample of the count matrices
+    idx = np.random.default_rng(1).choice(len(q), 400, replace=False)
+    for qi in idx:
+        if r0[qi, 1] == 0:
+            continue
+        for t in range(3):
+            assert np.linalg.matrix_rank(d0["cmats"][qi, t].astype(np.float64)) == d1["ranks"][qi, t]

@@ -29,7 +29,7 @@ SYMBOLS = [
     "tq_create", "tq_destroy", "tq_last_error", "tq_set_data", "tq_resolve",
     "tq_set_source", "tq_bootstrap", "tq_get_data", "tq_data_shape",
     "tq_resolve_dev", "tq_resolve_range_dev", "tq_unrank_dev", "tq_resolve_debug",
-    "tq_timing_enable", "tq_timing_read", "tq_timing_read_split", "tq_set_option", "tq_device_info",
+    "tq_timing_enable", "tq_timing_read", "tq_timing_read_split", "tq_set_option", "tq_device_info", "tq_debug_fetch",
 ]
 
 
@@ -108,6 +108,8 @@ def load() -> ctypes.CDLL:
     lib.tq_timing_read_split.argtypes = [vp, c.POINTER(c.c_double), c.POINTER(c.c_double),
                                          c.POINTER(c.c_double), c.POINTER(i64)]
     lib.tq_timing_read_split.restype = i32
+    lib.tq_debug_fetch.argtypes = [vp, i32, vp, i64]
+    lib.tq_debug_fetch.restype = i32
     lib.tq_set_option.argtypes = [vp, c.c_char_p, i64]
     lib.tq_set_option.restype = i32
     lib.tq_device_info.argtypes = [vp, c.POINTER(c.c_int32), c.POINTER(c.c_int32), c.POINTER(i64)]

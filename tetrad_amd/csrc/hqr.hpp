@@ -107,6 +107,18 @@ tq_bidiag_kernel(const uint32_t *__restrict__ cm, int64_t Q, double *__restrict_
                     }
                 }
             }
+            // Columns / rows whose norm is below 1e-20 * ||M||_F are treated as exactly zero (no
+            // reflector, d or e = 0).  Without this a zero column that picked up rounding residue
+            // (~1e-17) is "reflected", the next one shrinks to ~1e-33, ... and after ten such
+            // columns the squared norms reach the denormal range, 1/den overflows and the rest of
+            // the matrix is destroyed (found by the sparse-data stress test against the Jacobi path).
+            double f2 = 0.0;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) f2 = fma(a[s][r], a[s][r], f2);
+            }
+            const double thr2 = quad_sum(f2) * 1e-40;
             // d[K] / e[K] are stored as soon as they are known (keeping 32 more f64 live would cost
             // the kernel its second wave per SIMD)
             double *dout = de + (myq * 3 + t) * 32;
@@ -123,12 +135,13 @@ tq_bidiag_kernel(const uint32_t *__restrict__ cm, int64_t Q, double *__restrict_
                     double n2 = 0.0;
 #pragma unroll
                     for (int r = K; r < 16; ++r) n2 = fma(v[r], v[r], n2);
+                    const bool live = n2 > thr2;
                     const double nrm = sqrt_nr(n2);
                     const double x0 = v[K];
-                    const double alpha = (x0 < 0.0) ? nrm : -nrm;
+                    const double alpha = live ? ((x0 < 0.0) ? nrm : -nrm) : 0.0;
                     v[K] = x0 - alpha;
-                    const double den = fma(-alpha, x0, n2);      // = |v|^2 / 2 > 0 unless the column is zero
-                    const double beta = n2 > 0.0 ? rcp_nr<2>(den) : 0.0;
+                    const double den = fma(-alpha, x0, n2);      // = |v|^2 / 2 > 0 for a live column
+                    const double beta = live ? rcp_nr<2>(den) : 0.0;
                     if (writer) dout[K] = alpha;
 #pragma unroll
                     for (int s = so; s < 4; ++s) {
@@ -152,11 +165,12 @@ tq_bidiag_kernel(const uint32_t *__restrict__ cm, int64_t Q, double *__restrict_
                         p = fma(y[s], y[s], p);
                     }
                     const double n2 = quad_sum(p);
+                    const bool live = n2 > thr2;
                     const double x0 = quad_bcast<c1>(y[s1]);
                     const double nrm = sqrt_nr(n2);
-                    const double alpha = (x0 < 0.0) ? nrm : -nrm;
+                    const double alpha = live ? ((x0 < 0.0) ? nrm : -nrm) : 0.0;
                     const double den = fma(-alpha, x0, n2);
-                    const double beta = n2 > 0.0 ? rcp_nr<2>(den) : 0.0;
+                    const double beta = live ? rcp_nr<2>(den) : 0.0;
                     if (c == c1) y[s1] = x0 - alpha;
                     if (writer) dout[16 + K1] = alpha;
 #pragma unroll

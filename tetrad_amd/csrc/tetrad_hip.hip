@@ -964,6 +964,18 @@ int tq_data_shape(tq_ctx *ctx, int64_t *T, int64_t *S)
     return TQ_OK;
 }
 
+int tq_debug_fetch(tq_ctx *ctx, int which, void *dst, int64_t bytes)
+{
+    if (!ctx || !dst || bytes < 0) return TQ_ERR_INVALID_ARG;
+    const void *src = which == 0 ? (const void *)ctx->d_cm : which == 1 ? (const void *)ctx->d_de
+                      : which == 2 ? (const void *)ctx->d_sv : nullptr;
+    if (!src) return fail(ctx, TQ_ERR_INVALID_ARG, "tq_debug_fetch: nothing to fetch (which=%d)", which);
+    TQ_HIP(ctx, hipSetDevice(ctx->device));
+    TQ_HIP(ctx, hipDeviceSynchronize());
+    TQ_HIP(ctx, hipMemcpy(dst, src, (size_t)bytes, hipMemcpyDeviceToHost));
+    return TQ_OK;
+}
+
 int tq_device_info(tq_ctx *ctx, int32_t *num_cu, int32_t *waves_per_cu, int64_t *row_pitch)
 {
     if (!ctx) return TQ_ERR_INVALID_ARG;

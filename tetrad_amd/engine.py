@@ -160,6 +160,14 @@ class QuartetEngine:
             self._h, ctypes.byref(tot), ctypes.byref(a), ctypes.byref(b), ctypes.byref(n)))
         return tot.value, a.value, b.value, n.value
 
+    def debug_fetch(self, which: str, n: int) -> np.ndarray:
+        """Scratch of the last resolve call (test hook): 'cm' u32[n,256], 'de' f64[3n,32], 'sv' f64[3n,16]."""
+        shape, dt, code = {"cm": ((n, 256), np.uint32, 0), "de": ((3 * n, 32), np.float64, 1),
+                           "sv": ((3 * n, 16), np.float64, 2)}[which]
+        out = np.zeros(shape, dt)
+        self._check(self._lib.tq_debug_fetch(self._h, code, _ptr(out), out.nbytes))
+        return out
+
     def device_info(self):
         cu = ctypes.c_int32()
         w = ctypes.c_int32()

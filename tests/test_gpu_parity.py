@@ -317,3 +317,22 @@ def test_hqr_and_jacobi_agree_on_stress_data(oracle, T, S, seed, p, missing, sub
             continue
         for t in range(3):
             assert np.linalg.matrix_rank(d0["cmats"][qi, t].astype(np.float64)) == d1["ranks"][qi, t]
+
+
+def test_unsorted_and_repeated_taxon_indices(engine, oracle):
+    """The reference accepts any four row indices (order matters, repeats allowed); so must the engine."""
+    from tetrad_amd import synth
+    tmparr, tmpmap = synth.simulate_tmparr(11, 2500, seed=31, p=0.08, missing=0.15)
+    rng = np.random.default_rng(8)
+    q = rng.integers(0, 11, size=(600, 4)).astype(np.uint32)
+    engine.set_data(tmparr, tmpmap)
+    for sub in (True, False):
+        rstat, rscor, flags, dbg = engine.resolve(q, sub, debug=True)
+        _, o_rstat, o_rscor, o = oracle.new_infer_resolved_quartets(tmparr, tmpmap, q, sub, debug=True)
+        np.testing.assert_array_equal(dbg["cmats"], o["cmats"])
+        np.testing.assert_array_equal(rstat[:, 1], o_rstat[:, 1])
+        np.testing.assert_array_equal((flags & 1).astype(bool), (o["flags"] & 1).astype(bool))
+        smax = np.maximum(o["svds"].max(axis=(1, 2)), 1e-300)
+        assert_close(rscor, o_rscor, smax[:, None], "scores")
+        ok = ((flags | o["flags"]) & 3) == 0
+        np.testing.assert_array_equal(rstat[ok, 0], o_rstat[ok, 0])

@@ -1,0 +1,19 @@
+"""PCIe-inclusive throughput of the host-buffer API at c3 size (warm)."""
+import sys, time
+sys.path.insert(0,'/root/repo')
+import numpy as np, torch
+from tetrad_amd import synth
+from tetrad_amd.engine import QuartetEngine
+T,S,_=synth.CONFIGS["c3"]
+tmparr,tmpmap=synth.simulate_tmparr(T,S,103)
+Q=1_000_000
+q=synth.random_quartets(T,Q,4242)
+eng=QuartetEngine(0); eng.set_data(tmparr,tmpmap)
+# host-buffer API (tq_resolve): quartets H2D + kernels + rows D2H, synchronous.  A chunked
+# 3-stage pipeline with pinned staging was tried and was 5-10 % SLOWER at every chunk size
+# (smaller launches + the extra host copy cost more than the overlap gains), so it was dropped.
+eng.resolve(q, True)
+ts=[]
+for _ in range(5):
+    t0=time.perf_counter(); r=eng.resolve(q, True); ts.append(time.perf_counter()-t0)
+print(f"tq_resolve, {Q} quartets: {min(ts)*1e3:7.2f} ms  {Q/min(ts)/1e6:6.2f} Mq/s (PCIe inclusive)")

@@ -336,3 +336,19 @@ def test_unsorted_and_repeated_taxon_indices(engine, oracle):
         assert_close(rscor, o_rscor, smax[:, None], "scores")
         ok = ((flags | o["flags"]) & 3) == 0
         np.testing.assert_array_equal(rstat[ok, 0], o_rstat[ok, 0])
+
+
+def test_many_taxa_small_sites(engine, oracle):
+    """T = 300 taxa (row offsets beyond the c4 shape), S barely above one 2048-site step."""
+    from tetrad_amd import synth
+    tmparr, tmpmap = synth.simulate_tmparr(300, 2100, seed=300, p=0.03, missing=0.1)
+    q = synth.random_quartets(300, 1500, seed=12)
+    engine.set_data(tmparr, tmpmap)
+    for sub in (True, False):
+        rstat, rscor, flags = engine.resolve(q, sub)
+        _, o_rstat, o_rscor, o = oracle.new_infer_resolved_quartets(tmparr, tmpmap, q, sub, debug=True)
+        np.testing.assert_array_equal(rstat[:, 1], o_rstat[:, 1])
+        smax = np.maximum(o["svds"].max(axis=(1, 2)), 1e-300)
+        assert_close(rscor, o_rscor, smax[:, None], "scores")
+        ok = ((flags | o["flags"]) & 3) == 0
+        np.testing.assert_array_equal(rstat[ok, 0], o_rstat[ok, 0])

@@ -340,33 +340,28 @@ tq_scan_wg_kernel(DevData d, const uint32_t *__restrict__ quartets, const uint32
         const uint32_t sh_step = ld_bytes ? (uint32_t)TILE : (uint32_t)(WAVE * 16);
         const int slot = ld_bytes ? tid : 128 + (w - 2) * 64 + lane;          // abp panels 0-127, planes a 128-191, b 192-255
 
-        auto fetch_shared = [&](int tile, uint4 &x, uint4 &y) {
-            if (ld_bytes) {
-                x = ld16(rows, sh0 + (uint32_t)tile * sh_step);
-                y = ld16(rows, sh1 + (uint32_t)tile * sh_step);
-            } else if (ld_planes) {
-                x = ld16(sh_base, sh0 + (uint32_t)tile * sh_step);
-            }
+        // (values are passed and returned by value: address-taken locals end up in scratch memory,
+        // which costs a memory round trip per step)
+        auto fetch_x = [=](int tile) -> uint4 {
+            if (ld_bytes) return ld16(rows, sh0 + (uint32_t)tile * sh_step);
+            if (ld_planes) return ld16(sh_base, sh0 + (uint32_t)tile * sh_step);
+            return make_uint4(0, 0, 0, 0);
         };
-        auto store_shared = [&](int buf, const uint4 &x, const uint4 &y) {
-            if (ld_bytes) {
-                uint4 p;
-                p.x = (((x.x << 2) + y.x) << 4);
-                p.y = (((x.y << 2) + y.y) << 4);
-                p.z = (((x.z << 2) + y.z) << 4);
-                p.w = (((x.w << 2) + y.w) << 4);
-                shared_ab[buf][slot] = p;
-            } else if (ld_planes) {
-                shared_ab[buf][slot] = x;
-            }
+        auto fetch_y = [=](int tile) -> uint4 {
+            if (ld_bytes) return ld16(rows, sh1 + (uint32_t)tile * sh_step);
+            return make_uint4(0, 0, 0, 0);
+        };
+        auto combine = [=](uint4 x, uint4 y) -> uint4 {          // what goes into the LDS image
+            if (!ld_bytes) return x;
+            return make_uint4(((x.x << 2) + y.x) << 4, ((x.y << 2) + y.y) << 4, ((x.z << 2) + y.z) << 4,
+                              ((x.w << 2) + y.w) << 4);
         };
 
         // prologue: step 0 into buffer 0
-        uint4 sx = make_uint4(0, 0, 0, 0), sy = sx;
-        fetch_shared(0, sx, sy);
+        uint4 sx = fetch_x(0), sy = fetch_y(0);
         OwnRegs A, B;
         load_own(A, nib, planes, oo, 0);
-        store_shared(0, sx, sy);
+        if (ld_bytes | ld_planes) shared_ab[0][slot] = combine(sx, sy);
         uint32_t tile_carry = 0;
         __syncthreads();
 
@@ -404,24 +399,26 @@ tq_scan_wg_kernel(DevData d, const uint32_t *__restrict__ quartets, const uint32
             // ---- even step: prefetch t+1 (own -> B, shared -> registers), process A ----
             {
                 const int tn = min(t + 1, last);
-                fetch_shared(tn, sx, sy);
+                sx = fetch_x(tn);
+                sy = fetch_y(tn);
                 load_own(B, nib, planes, oo, tn);
                 __builtin_amdgcn_sched_barrier(0);
                 step(A, t);
                 __builtin_amdgcn_sched_barrier(0);
-                store_shared((t + 1) & 1, sx, sy);
+                if (ld_bytes | ld_planes) shared_ab[(t + 1) & 1][slot] = combine(sx, sy);
                 if (METHOD != 3) __syncthreads();      // METHOD 3 = timing diagnostic without the barrier
             }
             if (t + 1 >= d.ntiles) break;
             // ---- odd step ----
             {
                 const int tn = min(t + 2, last);
-                fetch_shared(tn, sx, sy);
+                sx = fetch_x(tn);
+                sy = fetch_y(tn);
                 load_own(A, nib, planes, oo, tn);
                 __builtin_amdgcn_sched_barrier(0);
                 step(B, t + 1);
                 __builtin_amdgcn_sched_barrier(0);
-                store_shared(t & 1, sx, sy);
+                if (ld_bytes | ld_planes) shared_ab[t & 1][slot] = combine(sx, sy);
                 if (METHOD != 3) __syncthreads();
             }
         }

@@ -265,7 +265,7 @@ def test_pipeline_options_do_not_change_results(engine):
     q = np.tile(g["quartets"], (3, 1))
     base = engine.resolve(q, True)
     try:
-        for opts in ({"overlap": 1024}, {"scan_wg": 0}, {"order": 0}, {"batch": 700}, {"scan_method": 0},
+        for opts in ({"overlap": 1024}, {"scan_wg": 1}, {"scan_wg": 2}, {"scan_wg": 8}, {"scan_wg": 16}, {"order": 0}, {"batch": 700}, {"scan_method": 0},
                      {"overlap": 512, "ov_scan_wgs": 2, "ov_svd_waves": 4}):
             for k, v in opts.items():
                 engine.set_option(k, v)
@@ -273,10 +273,10 @@ def test_pipeline_options_do_not_change_results(engine):
             for a, b in zip(base, got):
                 np.testing.assert_array_equal(a, b)
             for k in opts:
-                engine.set_option(k, {"scan_wg": 8, "order": 1, "scan_method": -1, "ov_scan_wgs": 1,
+                engine.set_option(k, {"scan_wg": 0, "order": 1, "scan_method": -1, "ov_scan_wgs": 1,
                                       "ov_svd_waves": 6}.get(k, 0))
     finally:
-        for k, v in (("overlap", 0), ("scan_wg", 8), ("order", 1), ("batch", 0), ("scan_method", -1)):
+        for k, v in (("overlap", 0), ("scan_wg", 0), ("order", 1), ("batch", 0), ("scan_method", -1)):
             engine.set_option(k, v)
 
 

@@ -281,7 +281,7 @@ __global__ void __launch_bounds__(NW *WAVE)
 tq_scan_wg_kernel(DevData d, const uint32_t *__restrict__ quartets, const uint32_t *__restrict__ order, int64_t Q,
                   uint32_t *__restrict__ cm)
 {
-    static_assert(NW >= 4, "waves 0-3 are the cooperative loaders");
+    static_assert(NW >= 1 && NW <= 16, "waves per workgroup");
     __shared__ uint4 shared_ab[2][SHARED_SLOTS];
     __shared__ uint32_t hist_all[NW][256];
     __shared__ uint32_t park_all[NW][WAVE * PAT_STRIDE / 4];
@@ -298,9 +298,9 @@ tq_scan_wg_kernel(DevData d, const uint32_t *__restrict__ quartets, const uint32
     const uint8_t *nib = d.nib;
     const uint8_t *planes = reinterpret_cast<const uint8_t *>(d.planes);
     const uint32_t pitch = (uint32_t)d.pitch, npitch = pitch / 2, wpitch = (uint32_t)d.W * 16u;
-    // cooperative roles (wave-uniform): waves 0,1 = code-byte panels 0,1 of rows a and b -> abp;
-    // wave 2 = plane records of a; wave 3 = plane records of b; other waves load nothing shared
-    const bool ld_bytes = w < 2, ld_planes = (w == 2) | (w == 3);
+    // cooperative jobs per step: 0,1 = code-byte panels 0,1 of rows a and b -> abp panels;
+    // 2 = plane records of a; 3 = plane records of b.  Wave w takes the jobs j with j % NW == w.
+    constexpr int NJOB = 4, JPW = (NJOB + NW - 1) / NW;        // jobs per wave
     __syncthreads();
 
     for (int64_t blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
@@ -330,38 +330,38 @@ tq_scan_wg_kernel(DevData d, const uint32_t *__restrict__ quartets, const uint32
         oo.d = qd * npitch + (uint32_t)lane * 16u;
         oo.pc = qc * wpitch + (uint32_t)lane * 16u;
         oo.pd = qd * wpitch + (uint32_t)lane * 16u;
-        // cooperative loads of this thread: two 16-byte pieces
-        //   waves 0,1: the same 16 code bytes of row a and of row b (panel w)  -> one abp piece
-        //   wave 2/3 : plane record of a / b for lane `lane`
-        const uint32_t sh0 = ld_bytes ? la * pitch + (uint32_t)w * 1024u + (uint32_t)lane * 16u
-                                      : (w == 2 ? la : lb) * wpitch + (uint32_t)lane * 16u;
-        const uint32_t sh1 = lb * pitch + (uint32_t)w * 1024u + (uint32_t)lane * 16u;
-        const uint8_t *sh_base = ld_bytes ? rows : planes;                    // wave-uniform
-        const uint32_t sh_step = ld_bytes ? (uint32_t)TILE : (uint32_t)(WAVE * 16);
-        const int slot = ld_bytes ? tid : 128 + (w - 2) * 64 + lane;          // abp panels 0-127, planes a 128-191, b 192-255
-
-        // (values are passed and returned by value: address-taken locals end up in scratch memory,
-        // which costs a memory round trip per step)
-        auto fetch_x = [=](int tile) -> uint4 {
-            if (ld_bytes) return ld16(rows, sh0 + (uint32_t)tile * sh_step);
-            if (ld_planes) return ld16(sh_base, sh0 + (uint32_t)tile * sh_step);
+        // cooperative loads of this thread (values are passed and returned by value: address-taken
+        // locals end up in scratch memory, which costs a memory round trip per step)
+        auto job_of = [=](int i) { return w + i * NW; };                       // wave-uniform
+        auto fetch_x = [=](int job, int tile) -> uint4 {
+            if (job < 2) return ld16(rows, la * pitch + (uint32_t)job * 1024u + (uint32_t)lane * 16u + (uint32_t)tile * TILE);
+            if (job < NJOB) return ld16(planes, (job == 2 ? la : lb) * wpitch + (uint32_t)lane * 16u + (uint32_t)tile * (WAVE * 16));
             return make_uint4(0, 0, 0, 0);
         };
-        auto fetch_y = [=](int tile) -> uint4 {
-            if (ld_bytes) return ld16(rows, sh1 + (uint32_t)tile * sh_step);
+        auto fetch_y = [=](int job, int tile) -> uint4 {
+            if (job < 2) return ld16(rows, lb * pitch + (uint32_t)job * 1024u + (uint32_t)lane * 16u + (uint32_t)tile * TILE);
             return make_uint4(0, 0, 0, 0);
         };
-        auto combine = [=](uint4 x, uint4 y) -> uint4 {          // what goes into the LDS image
-            if (!ld_bytes) return x;
+        auto combine = [=](int job, uint4 x, uint4 y) -> uint4 {               // what goes into the LDS image
+            if (job >= 2) return x;
             return make_uint4(((x.x << 2) + y.x) << 4, ((x.y << 2) + y.y) << 4, ((x.z << 2) + y.z) << 4,
                               ((x.w << 2) + y.w) << 4);
         };
+        // LDS slot of a job's piece: abp panels 0-63 / 64-127, planes a 128-191, planes b 192-255
+        auto slot_of = [=](int job) { return job * 64 + lane; };
 
         // prologue: step 0 into buffer 0
-        uint4 sx = fetch_x(0), sy = fetch_y(0);
+        uint4 sx[JPW], sy[JPW];
+#pragma unroll
+        for (int i = 0; i < JPW; ++i) {
+            sx[i] = fetch_x(job_of(i), 0);
+            sy[i] = fetch_y(job_of(i), 0);
+        }
         OwnRegs A, B;
         load_own(A, nib, planes, oo, 0);
-        if (ld_bytes | ld_planes) shared_ab[0][slot] = combine(sx, sy);
+#pragma unroll
+        for (int i = 0; i < JPW; ++i)
+            if (job_of(i) < NJOB) shared_ab[0][slot_of(job_of(i))] = combine(job_of(i), sx[i], sy[i]);
         uint32_t tile_carry = 0;
         __syncthreads();
 
@@ -399,26 +399,36 @@ tq_scan_wg_kernel(DevData d, const uint32_t *__restrict__ quartets, const uint32
             // ---- even step: prefetch t+1 (own -> B, shared -> registers), process A ----
             {
                 const int tn = min(t + 1, last);
-                sx = fetch_x(tn);
-                sy = fetch_y(tn);
+#pragma unroll
+                for (int i = 0; i < JPW; ++i) {
+                    sx[i] = fetch_x(job_of(i), tn);
+                    sy[i] = fetch_y(job_of(i), tn);
+                }
                 load_own(B, nib, planes, oo, tn);
                 __builtin_amdgcn_sched_barrier(0);
                 step(A, t);
                 __builtin_amdgcn_sched_barrier(0);
-                if (ld_bytes | ld_planes) shared_ab[(t + 1) & 1][slot] = combine(sx, sy);
+#pragma unroll
+                for (int i = 0; i < JPW; ++i)
+                    if (job_of(i) < NJOB) shared_ab[(t + 1) & 1][slot_of(job_of(i))] = combine(job_of(i), sx[i], sy[i]);
                 if (METHOD != 3) __syncthreads();      // METHOD 3 = timing diagnostic without the barrier
             }
             if (t + 1 >= d.ntiles) break;
             // ---- odd step ----
             {
                 const int tn = min(t + 2, last);
-                sx = fetch_x(tn);
-                sy = fetch_y(tn);
+#pragma unroll
+                for (int i = 0; i < JPW; ++i) {
+                    sx[i] = fetch_x(job_of(i), tn);
+                    sy[i] = fetch_y(job_of(i), tn);
+                }
                 load_own(A, nib, planes, oo, tn);
                 __builtin_amdgcn_sched_barrier(0);
                 step(B, t + 1);
                 __builtin_amdgcn_sched_barrier(0);
-                if (ld_bytes | ld_planes) shared_ab[t & 1][slot] = combine(sx, sy);
+#pragma unroll
+                for (int i = 0; i < JPW; ++i)
+                    if (job_of(i) < NJOB) shared_ab[t & 1][slot_of(job_of(i))] = combine(job_of(i), sx[i], sy[i]);
                 if (METHOD != 3) __syncthreads();
             }
         }

@@ -89,7 +89,7 @@ struct tq_ctx {
     double *d_de = nullptr, *d_sv = nullptr;
     uint32_t *d_nsnps = nullptr;
     int svd_method = 1;             // 0 = one-sided Jacobi (tq_svd_kernel), 1 = Householder + bidiagonal QR
-    int scan_wg = 8;                // waves per workgroup of the cooperative scan kernel (0 = one wave per quartet)
+    int scan_wg = 4;                // waves per workgroup of the cooperative scan kernel (1 = one wave per quartet)
     // software pipeline across sub-batches: scan of sub-batch i+1 runs on a second stream beside the
     // singular-value stage of sub-batch i (0 = off: one stage after the other on the caller's stream)
     int64_t overlap = 0;            // sub-batch size in quartets
@@ -287,15 +287,23 @@ int launch_scan_wg(tq_ctx *ctx, const uint32_t *dq, const uint32_t *order, int64
 int launch_scan_n(tq_ctx *ctx, const uint32_t *dq, const uint32_t *order, int64_t Q, int subsample,
                   hipStream_t stream)
 {
-    if (ctx->scan_wg == 8 && Q >= 64 && (uint64_t)ctx->T * (uint64_t)ctx->Sp < 0xFFFF0000ull) {
+    if (ctx->scan_wg >= 2 && Q >= 64 && (uint64_t)ctx->T * (uint64_t)ctx->Sp < 0xFFFF0000ull) {
         const int m = ctx->scan_method < 0 ? (subsample ? 1 : 0) : ctx->scan_method;
-        if (m == 2) return launch_scan_wg<true, 2, 8>(ctx, dq, order, Q, stream);   // diagnostic
-        if (m == 3) return launch_scan_wg<true, 3, 8>(ctx, dq, order, Q, stream);   // diagnostic
-        if (subsample)
-            return m ? launch_scan_wg<true, 1, 8>(ctx, dq, order, Q, stream)
-                     : launch_scan_wg<true, 0, 8>(ctx, dq, order, Q, stream);
-        return m ? launch_scan_wg<false, 1, 8>(ctx, dq, order, Q, stream)
-                 : launch_scan_wg<false, 0, 8>(ctx, dq, order, Q, stream);
+#define TQ_WG_CASE(NW)                                                                                   \
+    if (ctx->scan_wg == NW) {                                                                            \
+        if (m == 2) return launch_scan_wg<true, 2, NW>(ctx, dq, order, Q, stream);                       \
+        if (m == 3) return launch_scan_wg<true, 3, NW>(ctx, dq, order, Q, stream);                       \
+        if (subsample)                                                                                   \
+            return m ? launch_scan_wg<true, 1, NW>(ctx, dq, order, Q, stream)                            \
+                     : launch_scan_wg<true, 0, NW>(ctx, dq, order, Q, stream);                           \
+        return m ? launch_scan_wg<false, 1, NW>(ctx, dq, order, Q, stream)                               \
+                 : launch_scan_wg<false, 0, NW>(ctx, dq, order, Q, stream);                              \
+    }
+        TQ_WG_CASE(2)
+        TQ_WG_CASE(4)
+        TQ_WG_CASE(16)
+        TQ_WG_CASE(8)
+#undef TQ_WG_CASE
     }
 #define TQ_SCAN_CASE(N)                                                                              \
     case N:                                                                                          \
@@ -468,7 +476,7 @@ int launch_overlapped(tq_ctx *ctx, const uint32_t *dq, int64_t Q, int subsample,
         const uint32_t *order = nullptr;
         rc = make_order(ctx, dq + q0 * 4, n, ctx->sA, &order);
         if (!rc) {
-            ctx->wpc_override = ctx->ov_scan_wgs * 8;
+            ctx->wpc_override = ctx->ov_scan_wgs * (ctx->scan_wg > 1 ? ctx->scan_wg : 8);
             rc = launch_scan_n(ctx, dq + q0 * 4, order, n, subsample, ctx->sA);
         }
         if (!rc && hipEventRecord(ctx->evA[b], ctx->sA) != hipSuccess) rc = TQ_ERR_HIP;
@@ -786,8 +794,9 @@ int tq_set_option(tq_ctx *ctx, const char *name, int64_t value)
         return TQ_OK;
     }
     if (!strcmp(name, "scan_wg")) {
-        if (value != 0 && value != 8) return fail(ctx, TQ_ERR_INVALID_ARG, "scan_wg must be 0 or 8");
-        ctx->scan_wg = (int)value;
+        if (value != 0 && value != 1 && value != 2 && value != 4 && value != 8 && value != 16)
+            return fail(ctx, TQ_ERR_INVALID_ARG, "scan_wg must be 0 (default), 1, 2, 4, 8 or 16");
+        ctx->scan_wg = value ? (int)value : 4;
         return TQ_OK;
     }
     if (!strcmp(name, "svd_method")) {

@@ -27,7 +27,7 @@ def main():
     ap.add_argument("--methods", default="1")
     ap.add_argument("--orders", default="1")
     ap.add_argument("--svds", default="1", help="svd_method list: 0 Jacobi, 1 HQR")
-    ap.add_argument("--wgs", default="8", help="scan_wg list: 0 one wave per quartet, 8 cooperative")
+    ap.add_argument("--wgs", default="4", help="scan_wg list: 1 one wave per quartet; 2/4/8/16 waves per cooperative workgroup")
     ap.add_argument("--sort", default="none", choices=["none", "ab", "lex", "same"], help="order of the quartet list")
     args = ap.parse_args()
     import torch

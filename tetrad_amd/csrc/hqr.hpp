@@ -198,6 +198,7 @@ tq_bidiag_kernel(const uint32_t *__restrict__ cm, int64_t Q, double *__restrict_
 #define W_(i) wl[(i) * WAVE]
 #define E_(i) el[(i) * WAVE]
 __device__ __forceinline__ double hypot_nr(double a, double b) { return sqrt_nr(fma(a, a, b * b)); }
+constexpr int RSQ_NR = 2;      // Newton steps on v_rsq_f64 inside a rotation (1: 5e-15, 2: 1e-16 relative)
 
 __global__ void __launch_bounds__(WAVE)
 tq_bdsqr_kernel(const double *__restrict__ de, int64_t nmat, double *__restrict__ sv)
@@ -230,54 +231,54 @@ tq_bdsqr_kernel(const double *__restrict__ de, int64_t nmat, double *__restrict_
             negE |= (uint32_t)(fabs(ev[i]) <= tiny) << i;
             negW |= (uint32_t)(fabs(dv[i]) <= tiny) << i;
         }
-#define SET_E(i, v) do { const double v_ = (v); E_(i) = v_; negE = (negE & ~(1u << (i))) | ((uint32_t)(fabs(v_) <= tiny) << (i)); } while (0)
-#define SET_W(i, v) do { const double v_ = (v); W_(i) = v_; negW = (negW & ~(1u << (i))) | ((uint32_t)(fabs(v_) <= tiny) << (i)); } while (0)
-        // Every lane walks its own deflation index k: a lane whose current singular value has
-        // converged moves on at once instead of waiting for the slowest lane of the wave at that k.
-        int k = 15, its = 0;
-        while (k >= 0) {
-            // split point l = largest l <= k with e[l] negligible (or l == 0), unless a negligible
-            // w[l-1] is met first (then e[l] has to be chased out of the block: "cancel")
-            const uint32_t stopE = negE | 1u, stopW = negW << 1;
-            const uint32_t stops = (stopE | stopW) & ((2u << k) - 1u);
-            const int l = 31 - __builtin_clz(stops);
-            const bool cancel = ((stopE >> l) & 1u) == 0;
-            if (cancel) {
-                double cc = 0.0, ss = 1.0;
-                for (int i = l; i <= k; ++i) {
-                    const double ei = E_(i);
-                    const double f = ss * ei;
-                    SET_E(i, cc * ei);
-                    if (fabs(f) <= tiny) break;
-                    const double g = W_(i);
-                    const double h = hypot_nr(f, g);
-                    SET_W(i, h);
-                    const double hi = rcp_nr<2>(h);
-                    cc = g * hi;
-                    ss = -f * hi;
+#define SET_E(i, v) do { const double v_ = (v); E_(i) = v_; const uint32_t b_ = 1u << (i); negE = (negE & ~b_) | (fabs(v_) <= tiny ? b_ : 0u); } while (0)
+#define SET_W(i, v) do { const double v_ = (v); W_(i) = v_; const uint32_t b_ = 1u << (i); negW = (negW & ~b_) | (fabs(v_) <= tiny ? b_ : 0u); } while (0)
+        // Every lane walks its own deflation index k.  Converged values are popped in a short inner
+        // loop that touches registers only, so a lane never spends a whole sweep slot of the wave on
+        // "k--" while its neighbours sweep.
+        int k = 15, its = 0, l = 0;
+        for (;;) {
+            for (;;) {
+                // split point l = largest l <= k with e[l] negligible (or l == 0), unless a negligible
+                // w[l-1] is met first (then e[l] has to be chased out of the block: "cancel")
+                const uint32_t stopE = negE | 1u, stopW = negW << 1;
+                const uint32_t stops = (stopE | stopW) & ((2u << k) - 1u);
+                l = 31 - __builtin_clz(stops);
+                if (((stopE >> l) & 1u) == 0) {                       // cancel (rare)
+                    double cc = 0.0, ss = 1.0;
+                    for (int i = l; i <= k; ++i) {
+                        const double ei = E_(i);
+                        const double f = ss * ei;
+                        SET_E(i, cc * ei);
+                        if (fabs(f) <= tiny) break;
+                        const double g = W_(i);
+                        const double h = hypot_nr(f, g);
+                        SET_W(i, h);
+                        const double hi = rcp_nr<2>(h);
+                        cc = g * hi;
+                        ss = -f * hi;
+                    }
                 }
-            }
-            double z = W_(k);
-            if (l == k || its >= 60) {          // converged (or iteration cap: keep what we have)
-                W_(k) = fabs(z);
-                --k;
+                if (l != k && its < 60) break;      // a block of >= 2 values that still needs sweeps
+                if (--k < 0) break;                 // converged (or iteration cap: keep what we have)
                 its = 0;
-                continue;
             }
+            if (k < 0) break;
             ++its;
             // shift from the bottom 2x2 minor
-            double x = W_(l);
             const int nm = k - 1;
+            double x = W_(l);
             double y = W_(nm);
             double g = E_(nm);
             double h = E_(k);
+            const double z = W_(k);
             double f = ((y - z) * (y + z) + (g - h) * (g + h)) * rcp_nr<2>(2.0 * h * y);
             g = hypot_nr(f, 1.0);
             f = ((x - z) * (x + z) + h * (y * rcp_nr<2>(f + copysign(g, f)) - h)) * rcp_nr<2>(x);
             double cc = 1.0, ss = 1.0;
-            // one QR sweep over the block [l,k]; the LDS reads of the next step are issued
-            // before the current step's arithmetic, and each hypot shares one rsq with the
-            // reciprocal its rotation needs
+            // one QR sweep over the block [l,k]; the LDS reads of the next step are issued before the
+            // current step's arithmetic, each hypot shares one rsq with the reciprocal its rotation
+            // needs, and a zero pivot is a select, not a branch (f = h = 0 there, so c = s = 0 * rz)
             double gn = E_(l + 1), yn = W_(l + 1);
             for (int jj = l; jj <= nm; ++jj) {
                 g = gn;
@@ -288,7 +289,7 @@ tq_bdsqr_kernel(const double *__restrict__ de, int64_t nmat, double *__restrict_
                 h = ss * g;
                 g = cc * g;
                 double zz = fma(f, f, h * h);
-                double rz = zz > 0.0 ? rsq_nr<2>(zz) : 0.0;
+                double rz = rsq_nr<RSQ_NR>(fmax(zz, 1e-290));
                 SET_E(jj, zz * rz);
                 cc = f * rz;
                 ss = h * rz;
@@ -297,12 +298,11 @@ tq_bdsqr_kernel(const double *__restrict__ de, int64_t nmat, double *__restrict_
                 h = y * ss;
                 y *= cc;
                 zz = fma(f, f, h * h);
-                rz = zz > 0.0 ? rsq_nr<2>(zz) : 0.0;
+                rz = rsq_nr<RSQ_NR>(fmax(zz, 1e-290));
                 SET_W(jj, zz * rz);
-                if (zz > 0.0) {
-                    cc = f * rz;
-                    ss = h * rz;
-                }
+                const bool nz = zz > 0.0;
+                cc = nz ? f * rz : cc;
+                ss = nz ? h * rz : ss;
                 f = fma(cc, g, ss * y);
                 x = fma(cc, y, -(ss * g));
             }

@@ -148,7 +148,9 @@ int tq_timing_read_split(tq_ctx *ctx, double *total_ms, double *scan_ms, double 
 
 /* Tuning / diagnostic knobs (value 0 = library default unless noted).  Returns TQ_OK or an error.
  * Names: nrep, waves_per_cu, batch, order, scan_wg (waves per scan workgroup: 1, 2, 4, 8, 16), scan_method (-1 auto), svd_method (0 Jacobi,
- * 1 Householder+QR), overlap, ov_scan_wgs, ov_svd_waves, phases (timing diagnostics).           */
+ * 1 Householder+QR), xcd_remap (1: scan workgroups of one XCD take a contiguous part of the sorted order),
+ * svd_wpc (blocks per CU of the singular-value grids, 0 = one pass per block), overlap, ov_scan_wgs,
+ * ov_svd_waves, phases (timing diagnostics).                                                     */
 int tq_set_option(tq_ctx *ctx, const char *name, int64_t value);
 
 /* Test hook: copy the scratch of the last resolve call to the host.  which = 0: count slab

@@ -257,6 +257,27 @@ def test_c3_sample_vs_oracle(engine, oracle):
         assert_close(rscor, o_rscor, smax, "scores")
 
 
+@pytest.mark.parametrize("Q", [64, 65, 255, 257, 1001, 2047, 4100])
+def test_scan_grid_shapes(engine, Q):
+    """Batch sizes that do not fill the last workgroup / the last XCD chunk: the cooperative kernel
+    (one block per workgroup, XCD-contiguous ids) must give the rows of the one-wave-per-quartet
+    kernel.  A full-mode pass runs in between so that a skipped block would show stale counts."""
+    g = load_golden("c1_T16_S5000")
+    engine.set_data(g["tmparr"], g["tmpmap"])
+    rng = np.random.default_rng(Q)
+    q = g["quartets"][rng.integers(0, len(g["quartets"]), size=Q)]
+    try:
+        engine.set_option("scan_wg", 1)
+        want = engine.resolve(q, True)
+        engine.set_option("scan_wg", 0)
+        engine.resolve(q, False)
+        got = engine.resolve(q, True)
+    finally:
+        engine.set_option("scan_wg", 0)
+    for a, b in zip(want, got):
+        np.testing.assert_array_equal(a, b)
+
+
 def test_pipeline_options_do_not_change_results(engine):
     """Two-stream overlapped pipeline, per-wave scan kernel, natural order, small batches: all must
     give bitwise the same rows as the default configuration."""
@@ -265,7 +286,7 @@ def test_pipeline_options_do_not_change_results(engine):
     q = np.tile(g["quartets"], (3, 1))
     base = engine.resolve(q, True)
     try:
-        for opts in ({"overlap": 1024}, {"scan_wg": 1}, {"scan_wg": 2}, {"scan_wg": 8}, {"scan_wg": 16}, {"order": 0}, {"batch": 700}, {"scan_method": 0},
+        for opts in ({"overlap": 1024}, {"scan_wg": 1}, {"scan_wg": 2}, {"scan_wg": 8}, {"scan_wg": 16}, {"xcd_remap": 0}, {"waves_per_cu": 12}, {"svd_wpc": 8}, {"order": 0}, {"batch": 700}, {"scan_method": 0},
                      {"overlap": 512, "ov_scan_wgs": 2, "ov_svd_waves": 4}):
             for k, v in opts.items():
                 engine.set_option(k, v)
@@ -273,10 +294,10 @@ def test_pipeline_options_do_not_change_results(engine):
             for a, b in zip(base, got):
                 np.testing.assert_array_equal(a, b)
             for k in opts:
-                engine.set_option(k, {"scan_wg": 0, "order": 1, "scan_method": -1, "ov_scan_wgs": 1,
+                engine.set_option(k, {"scan_wg": 0, "xcd_remap": 1, "order": 1, "scan_method": -1, "ov_scan_wgs": 1,
                                       "ov_svd_waves": 6}.get(k, 0))
     finally:
-        for k, v in (("overlap", 0), ("scan_wg", 0), ("order", 1), ("batch", 0), ("scan_method", -1)):
+        for k, v in (("overlap", 0), ("scan_wg", 0), ("xcd_remap", 1), ("waves_per_cu", 0), ("svd_wpc", 0), ("order", 1), ("batch", 0), ("scan_method", -1)):
             engine.set_option(k, v)
 
 

@@ -198,7 +198,7 @@ tq_bidiag_kernel(const uint32_t *__restrict__ cm, int64_t Q, double *__restrict_
 #define W_(i) wl[(i) * WAVE]
 #define E_(i) el[(i) * WAVE]
 __device__ __forceinline__ double hypot_nr(double a, double b) { return sqrt_nr(fma(a, a, b * b)); }
-constexpr int RSQ_NR = 2;      // Newton steps on v_rsq_f64 inside a rotation (1: 5e-15, 2: 1e-16 relative)
+constexpr int RSQ_NR = 1;      // Newton steps on v_rsq_f64 inside a rotation (1: 5e-15, 2: 1e-16 relative)
 
 __global__ void __launch_bounds__(WAVE)
 tq_bdsqr_kernel(const double *__restrict__ de, int64_t nmat, double *__restrict__ sv)

@@ -279,7 +279,7 @@ constexpr int SHARED_SLOTS = 256;
 template <bool SUB, int METHOD, int NW>
 __global__ void __launch_bounds__(NW *WAVE)
 tq_scan_wg_kernel(DevData d, const uint32_t *__restrict__ quartets, const uint32_t *__restrict__ order, int64_t Q,
-                  uint32_t *__restrict__ cm)
+                  uint32_t *__restrict__ cm, int64_t xcd_chunk)
 {
     static_assert(NW >= 1 && NW <= 16, "waves per workgroup");
     __shared__ uint4 shared_ab[2][SHARED_SLOTS];
@@ -303,7 +303,17 @@ tq_scan_wg_kernel(DevData d, const uint32_t *__restrict__ quartets, const uint32
     constexpr int NJOB = 4, JPW = (NJOB + NW - 1) / NW;        // jobs per wave
     __syncthreads();
 
-    for (int64_t blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
+    const int64_t nslot = xcd_chunk > 0 ? 8 * xcd_chunk : nblk;
+    for (int64_t blk0 = blockIdx.x; blk0 < nslot; blk0 += gridDim.x) {
+        // Workgroup ids are dealt round-robin to the 8 XCDs (each with its own L2).  With xcd_chunk > 0
+        // the ids that land on one XCD walk one contiguous eighth of the sorted order, so a row pair
+        // (a,b) is pulled into one L2 instead of eight.
+        int64_t blk = blk0;
+        if (xcd_chunk > 0) {
+            const int64_t x = blk0 & 7, j = blk0 >> 3;
+            blk = x * xcd_chunk + j;
+            if (j >= xcd_chunk || blk >= nblk) continue;       // uniform for the whole workgroup
+        }
         // leader = first quartet of the block; its (a,b) is what the workgroup shares
         const int64_t it0 = blk * NW;
         const int64_t lqi = order ? (int64_t)order[it0] : it0;

@@ -28,6 +28,8 @@ def main():
     ap.add_argument("--orders", default="1")
     ap.add_argument("--svds", default="1", help="svd_method list: 0 Jacobi, 1 HQR")
     ap.add_argument("--wgs", default="4", help="scan_wg list: 1 one wave per quartet; 2/4/8/16 waves per cooperative workgroup")
+    ap.add_argument("--svdwpcs", default="0", help="svd_wpc list: blocks per CU of the bidiag/bdsqr grids (0 default)")
+    ap.add_argument("--xcd", type=int, default=0, help="xcd_remap option")
     ap.add_argument("--sort", default="none", choices=["none", "ab", "lex", "same"], help="order of the quartet list")
     args = ap.parse_args()
     import torch
@@ -47,6 +49,7 @@ def main():
     dev = torch.device("cuda:0")
     eng = QuartetEngine(0)
     eng.set_data(tmparr, tmpmap)
+    eng.set_option("xcd_remap", args.xcd)
     d_q = torch.from_numpy(quartets.astype(np.int32)).to(dev)
     d_rstat = torch.zeros((Q, 2), dtype=torch.int32, device=dev)
     d_rscor = torch.zeros((Q, 3), dtype=torch.float64, device=dev)
@@ -55,12 +58,13 @@ def main():
         args.modes.split(","), [int(x) for x in args.nreps.split(",")],
         [int(x) for x in args.wpcs.split(",")], [int(x) for x in args.methods.split(",")],
         [int(x) for x in args.orders.split(",")], [int(x) for x in args.svds.split(",")],
-        [int(x) for x in args.wgs.split(",")]))
+        [int(x) for x in args.wgs.split(",")], [int(x) for x in args.svdwpcs.split(",")]))
     times = {v: [] for v in variants}
     eng.timing_enable(True)
     for rnd in range(args.rounds + 1):
         for v in variants:
-            mode, nrep, wpc, meth, order, svdm, wgm = v
+            mode, nrep, wpc, meth, order, svdm, wgm, swpc = v
+            eng.set_option("svd_wpc", swpc)
             eng.set_option("scan_wg", wgm)
             eng.set_option("svd_method", svdm)
             eng.set_option("order", order)
@@ -73,10 +77,10 @@ def main():
             if rnd:                     # round 0 is warm-up
                 times[v].append((tot, scan, svd))
     print(f"# {args.config} T={T} S={S} Q={Q} rounds={args.rounds} sort={args.sort}")
-    print("mode nrep wpc meth ord svd  wg total_ms  scan_ms   svd_ms   Mq/s")
+    print("mode nrep wpc meth ord svd  wg swpc total_ms  scan_ms   svd_ms   Mq/s")
     for v in variants:
         t = np.array(times[v]).min(axis=0)
-        print(f"{v[0]:4s} {v[1]:4d} {v[2]:3d} {v[3]:4d} {v[4]:3d} {v[5]:3d} {v[6]:3d} {t[0]:9.3f} {t[1]:8.3f} {t[2]:8.3f} {Q / t[0] / 1e3:7.2f}")
+        print(f"{v[0]:4s} {v[1]:4d} {v[2]:3d} {v[3]:4d} {v[4]:3d} {v[5]:3d} {v[6]:3d} {v[7]:4d} {t[0]:9.3f} {t[1]:8.3f} {t[2]:8.3f} {Q / t[0] / 1e3:7.2f}")
 
 
 if __name__ == "__main__":

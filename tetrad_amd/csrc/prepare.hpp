@@ -68,15 +68,17 @@ __global__ void tq_unrank_kernel(const uint64_t *__restrict__ ranks, uint64_t fi
     reinterpret_cast<uint4 *>(quartets)[i] = v;
 }
 
-// sort key of a quartet: its first two taxa (quartets sharing them share two of their four rows)
-__global__ void tq_key_kernel(const uint32_t *__restrict__ quartets, int64_t Q, uint32_t T,
+// sort key of a quartet: its first two taxa (quartets sharing them share two of their four rows in
+// LDS), then -- when it fits 32 bits -- the third (neighbours then also find row c in the caches)
+__global__ void tq_key_kernel(const uint32_t *__restrict__ quartets, int64_t Q, uint32_t T, int with_c,
                               uint32_t *__restrict__ keys, uint32_t *__restrict__ idx)
 {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= Q) return;
     const uint4 q = reinterpret_cast<const uint4 *>(quartets)[i];
-    const uint32_t a = q.x < T ? q.x : T - 1, b = q.y < T ? q.y : T - 1;
-    keys[i] = a * T + b;
+    const uint32_t a = q.x < T ? q.x : T - 1, b = q.y < T ? q.y : T - 1, c = q.z < T ? q.z : T - 1;
+    const uint32_t ab = a * T + b;
+    keys[i] = with_c ? ab * T + c : ab;
     idx[i] = (uint32_t)i;
 }
 

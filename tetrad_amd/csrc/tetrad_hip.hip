@@ -212,11 +212,13 @@ int make_order(tq_ctx *ctx, const uint32_t *dq, int64_t n, hipStream_t stream, c
     if (!ctx->order || n < 1024 || ctx->T > 65535) return TQ_OK;
     uint32_t *keys_in = ctx->d_sort, *idx_in = keys_in + ctx->cm_quartets;
     uint32_t *keys_out = idx_in + ctx->cm_quartets, *idx_out = keys_out + ctx->cm_quartets;
+    const uint64_t T = (uint64_t)ctx->T;
+    const int with_c = T * T * T <= 0xFFFFFFFFull;
     hipLaunchKernelGGL(tq_key_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, dq, n,
-                       (uint32_t)ctx->T, keys_in, idx_in);
+                       (uint32_t)ctx->T, with_c, keys_in, idx_in);
     TQ_HIP(ctx, hipGetLastError());
     int bits = 1;
-    while (bits < 32 && (1ull << bits) < (uint64_t)ctx->T * (uint64_t)ctx->T) ++bits;
+    while (bits < 32 && (1ull << bits) < (with_c ? T * T * T : T * T)) ++bits;
     size_t tmp = ctx->sort_tmp_bytes;
     TQ_HIP(ctx, hipcub::DeviceRadixSort::SortPairs(ctx->d_sort_tmp, tmp, keys_in, keys_out, idx_in, idx_out, (int)n,
                                                    0, bits, stream));

@@ -68,7 +68,8 @@ __global__ void tq_boot_build_kernel(const uint8_t *__restrict__ seqarr, int64_t
                                      const uint32_t *__restrict__ src_col, const uint32_t *__restrict__ site_locus,
                                      int64_t S, int64_t Sp, int64_t W, int32_t T, uint64_t seed,
                                      uint8_t *__restrict__ rows, uint8_t *__restrict__ nib,
-                                     uint4 *__restrict__ planes)
+                                     uint4 *__restrict__ planes, uint32_t *__restrict__ planes3,
+                                     uint32_t *__restrict__ runbeg)
 {
     int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= (int64_t)T * W) return;
@@ -109,6 +110,7 @@ __global__ void tq_boot_build_kernel(const uint8_t *__restrict__ seqarr, int64_t
         b1 |= (uint32_t)((code >> 1) & 1) << i;
     }
     planes[t * W + w] = make_uint4(mm, b0, b1, rb);
+    store_planes3(planes3, runbeg, t, W, w, mm, b0, b1, rb);
     reinterpret_cast<uint4 *>(nib + t * (Sp / 2))[w] = make_uint4(nw[0], nw[1], nw[2], nw[3]);
 }
 

@@ -16,7 +16,9 @@ constexpr double DEGENERATE_REL_GAP = 1e-9;
 struct DevData {
     const uint8_t *rows;
     const uint8_t *nib;     // [T][Sp/2] two base codes per byte (see nib_offset)
-    const uint4 *planes;
+    const uint4 *planes;    // [T][W] {miss, p0, p1, runbeg}
+    const uint32_t *planes3; // [T][W][3] {miss, p0, p1}: the compact copy the cooperative scan streams
+    const uint32_t *runbeg;  // [W] run-begin bits (the same for every taxon)
     int64_t pitch;      // bytes per row (Sp)
     int64_t W;          // plane records per row (Sp/32)
     int32_t T;

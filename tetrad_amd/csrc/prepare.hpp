@@ -2,12 +2,23 @@
 // Part of the single translation unit tetrad_hip.hip (included inside its anonymous namespace).
 #pragma once
 
+__device__ __forceinline__ void store_planes3(uint32_t *planes3, uint32_t *runbeg, int64_t t, int64_t W, int64_t w,
+                                              uint32_t mm, uint32_t b0, uint32_t b1, uint32_t rb)
+{
+    uint32_t *p3 = planes3 + (t * W + w) * 3;
+    p3[0] = mm;
+    p3[1] = b0;
+    p3[2] = b1;
+    if (t == 0) runbeg[w] = rb;
+}
+
 // ------------------------------------------------------------------------------------
 // data preparation kernel: one thread per 32-site word of one taxon row
 // ------------------------------------------------------------------------------------
 __global__ void tq_prepare_rows(const uint8_t *__restrict__ raw, const uint32_t *__restrict__ locus,
                                 int64_t S, int64_t Sp, int64_t W, int32_t T, uint8_t *__restrict__ rows,
-                                uint8_t *__restrict__ nib, uint4 *__restrict__ planes)
+                                uint8_t *__restrict__ nib, uint4 *__restrict__ planes,
+                                uint32_t *__restrict__ planes3, uint32_t *__restrict__ runbeg)
 {
     int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= (int64_t)T * W) return;
@@ -32,6 +43,7 @@ __global__ void tq_prepare_rows(const uint8_t *__restrict__ raw, const uint32_t 
         }
     }
     planes[t * W + w] = make_uint4(mm, b0, b1, rb);
+    store_planes3(planes3, runbeg, t, W, w, mm, b0, b1, rb);
     reinterpret_cast<uint4 *>(nib + t * (Sp / 2))[w] = make_uint4(nw[0], nw[1], nw[2], nw[3]);
 }
 

@@ -250,19 +250,26 @@ __device__ __forceinline__ uint4 ld16(const uint8_t *base, uint32_t off)
     return *reinterpret_cast<const uint4 *>(base + off);
 }
 
-// per-lane byte offsets of a wave's own rows c, d (nibble array) and their plane records
+// 12-byte load (one compact plane record {miss, p0, p1}); .w of the result is 0
+__device__ __forceinline__ uint4 ld12(const uint8_t *base, uint32_t off)
+{
+    const uint3 v = *reinterpret_cast<const uint3 *>(base + off);
+    return make_uint4(v.x, v.y, v.z, 0u);
+}
+
+// per-lane byte offsets of a wave's own rows c, d (nibble array) and their compact plane records
 struct OwnOff {
     uint32_t c, d, pc, pd;
 };
 
-__device__ __forceinline__ void load_own(OwnRegs &r, const uint8_t *nib, const uint8_t *planes, const OwnOff &o,
+__device__ __forceinline__ void load_own(OwnRegs &r, const uint8_t *nib, const uint8_t *planes3, const OwnOff &o,
                                          int tile)
 {
-    const uint32_t tn = (uint32_t)tile * (TILE / 2), tp = (uint32_t)tile * (WAVE * 16);
+    const uint32_t tn = (uint32_t)tile * (TILE / 2), tp = (uint32_t)tile * (WAVE * 12);
     r.c = ld16(nib, o.c + tn);
     r.d = ld16(nib, o.d + tn);
-    r.pc = ld16(planes, o.pc + tp);
-    r.pd = ld16(planes, o.pd + tp);
+    r.pc = ld12(planes3, o.pc + tp);
+    r.pd = ld12(planes3, o.pd + tp);
 }
 
 // (c<<2|d) code bytes of 8 sites from one nibble dword of each row: lo = sites 0-3, hi = sites 4-7
@@ -297,9 +304,13 @@ tq_scan_wg_kernel(DevData d, const uint32_t *__restrict__ quartets, const uint32
     const uint8_t *rows = d.rows;
     const uint8_t *nib = d.nib;
     const uint8_t *planes = reinterpret_cast<const uint8_t *>(d.planes);
-    const uint32_t pitch = (uint32_t)d.pitch, npitch = pitch / 2, wpitch = (uint32_t)d.W * 16u;
-    // cooperative jobs per step: 0,1 = code-byte panels 0,1 of rows a and b -> abp panels;
-    // 2 = plane records of a; 3 = plane records of b.  Wave w takes the jobs j with j % NW == w.
+    const uint8_t *planes3 = reinterpret_cast<const uint8_t *>(d.planes3);
+    const uint8_t *runbeg = reinterpret_cast<const uint8_t *>(d.runbeg);
+    const uint32_t pitch = (uint32_t)d.pitch, npitch = pitch / 2, wpitch = (uint32_t)d.W * 16u,
+                   w3pitch = (uint32_t)d.W * 12u;
+    // cooperative jobs per step: 0,1 = nibble codes of rows a and b for sites 0-15 / 16-31 of every
+    // lane -> abp panels 0,1; 2 = plane record of a (+ run-begin bits); 3 = plane record of b.
+    // Wave w takes the jobs j with j % NW == w.
     constexpr int NJOB = 4, JPW = (NJOB + NW - 1) / NW;        // jobs per wave
     __syncthreads();
 
@@ -338,24 +349,32 @@ tq_scan_wg_kernel(DevData d, const uint32_t *__restrict__ quartets, const uint32
         OwnOff oo;
         oo.c = qc * npitch + (uint32_t)lane * 16u;
         oo.d = qd * npitch + (uint32_t)lane * 16u;
-        oo.pc = qc * wpitch + (uint32_t)lane * 16u;
-        oo.pd = qd * wpitch + (uint32_t)lane * 16u;
+        oo.pc = qc * w3pitch + (uint32_t)lane * 12u;
+        oo.pd = qd * w3pitch + (uint32_t)lane * 12u;
         // cooperative loads of this thread (values are passed and returned by value: address-taken
         // locals end up in scratch memory, which costs a memory round trip per step)
         auto job_of = [=](int i) { return w + i * NW; };                       // wave-uniform
+        auto ld8 = [=](const uint8_t *base, uint32_t off) -> uint2 { return *reinterpret_cast<const uint2 *>(base + off); };
         auto fetch_x = [=](int job, int tile) -> uint4 {
-            if (job < 2) return ld16(rows, la * pitch + (uint32_t)job * 1024u + (uint32_t)lane * 16u + (uint32_t)tile * TILE);
-            if (job < NJOB) return ld16(planes, (job == 2 ? la : lb) * wpitch + (uint32_t)lane * 16u + (uint32_t)tile * (WAVE * 16));
+            if (job < 2) {                                   // 8 nibble bytes (16 sites) of a and of b
+                const uint32_t o = (uint32_t)lane * 16u + (uint32_t)job * 8u + (uint32_t)tile * (TILE / 2);
+                const uint2 xa = ld8(nib, la * npitch + o), xb = ld8(nib, lb * npitch + o);
+                return make_uint4(xa.x, xa.y, xb.x, xb.y);
+            }
+            if (job < NJOB) return ld12(planes3, (job == 2 ? la : lb) * w3pitch + (uint32_t)lane * 12u + (uint32_t)tile * (WAVE * 12));
             return make_uint4(0, 0, 0, 0);
         };
         auto fetch_y = [=](int job, int tile) -> uint4 {
-            if (job < 2) return ld16(rows, lb * pitch + (uint32_t)job * 1024u + (uint32_t)lane * 16u + (uint32_t)tile * TILE);
+            if (job == 2) return make_uint4(*reinterpret_cast<const uint32_t *>(runbeg + (uint32_t)lane * 4u + (uint32_t)tile * (WAVE * 4)), 0, 0, 0);
             return make_uint4(0, 0, 0, 0);
         };
         auto combine = [=](int job, uint4 x, uint4 y) -> uint4 {               // what goes into the LDS image
-            if (job >= 2) return x;
-            return make_uint4(((x.x << 2) + y.x) << 4, ((x.y << 2) + y.y) << 4, ((x.z << 2) + y.z) << 4,
-                              ((x.w << 2) + y.w) << 4);
+            if (job == 2) return make_uint4(x.x, x.y, x.z, y.x);
+            if (job > 2) return x;
+            // x = {a.lo8, a.hi8, b.lo8, b.hi8} nibble words -> pattern partial ((a<<2)+b)<<4 of 16 sites
+            const uint32_t m = 0x0F0F0F0Fu;
+            return make_uint4((((x.x & m) << 2) + (x.z & m)) << 4, ((((x.x >> 4) & m) << 2) + ((x.z >> 4) & m)) << 4,
+                              (((x.y & m) << 2) + (x.w & m)) << 4, ((((x.y >> 4) & m) << 2) + ((x.w >> 4) & m)) << 4);
         };
         // LDS slot of a job's piece: abp panels 0-63 / 64-127, planes a 128-191, planes b 192-255
         auto slot_of = [=](int job) { return job * 64 + lane; };
@@ -368,7 +387,7 @@ tq_scan_wg_kernel(DevData d, const uint32_t *__restrict__ quartets, const uint32
             sy[i] = fetch_y(job_of(i), 0);
         }
         OwnRegs A, B;
-        load_own(A, nib, planes, oo, 0);
+        load_own(A, nib, planes3, oo, 0);
 #pragma unroll
         for (int i = 0; i < JPW; ++i)
             if (job_of(i) < NJOB) shared_ab[0][slot_of(job_of(i))] = combine(job_of(i), sx[i], sy[i]);
@@ -414,7 +433,7 @@ tq_scan_wg_kernel(DevData d, const uint32_t *__restrict__ quartets, const uint32
                     sx[i] = fetch_x(job_of(i), tn);
                     sy[i] = fetch_y(job_of(i), tn);
                 }
-                load_own(B, nib, planes, oo, tn);
+                load_own(B, nib, planes3, oo, tn);
                 __builtin_amdgcn_sched_barrier(0);
                 step(A, t);
                 __builtin_amdgcn_sched_barrier(0);
@@ -432,7 +451,7 @@ tq_scan_wg_kernel(DevData d, const uint32_t *__restrict__ quartets, const uint32
                     sx[i] = fetch_x(job_of(i), tn);
                     sy[i] = fetch_y(job_of(i), tn);
                 }
-                load_own(A, nib, planes, oo, tn);
+                load_own(A, nib, planes3, oo, tn);
                 __builtin_amdgcn_sched_barrier(0);
                 step(B, t + 1);
                 __builtin_amdgcn_sched_barrier(0);

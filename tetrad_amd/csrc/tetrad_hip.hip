@@ -62,8 +62,10 @@ struct tq_ctx {
     uint8_t *d_rows = nullptr;
     uint8_t *d_nib = nullptr;       // [T][Sp/2] nibble-packed copy of the rows (common.hpp: nib_offset)
     uint4 *d_planes = nullptr;      // [T][W] {miss, p0, p1, runbeg}
+    uint32_t *d_planes3 = nullptr;  // [T][W][3] {miss, p0, p1}, then runbeg [W]
     bool have_data = false;
     bool locus_runs_ok = false;
+    int64_t plane_cap_W = 0;        // W the planes3 / runbeg allocation was sized for
     int64_t data_capacity = 0;      // allocated Sp (rows/planes are re-used by bootstrap replicates)
     // bootstrap source (tq_set_source): ASCII seqarr [T][S0], spans i64 [nloci][2]
     uint8_t *d_seqarr = nullptr;
@@ -142,9 +144,11 @@ void free_data(tq_ctx *ctx)
     if (ctx->d_rows) (void)hipFree(ctx->d_rows);
     if (ctx->d_nib) (void)hipFree(ctx->d_nib);
     if (ctx->d_planes) (void)hipFree(ctx->d_planes);
+    if (ctx->d_planes3) (void)hipFree(ctx->d_planes3);
     ctx->d_rows = nullptr;
     ctx->d_nib = nullptr;
     ctx->d_planes = nullptr;
+    ctx->d_planes3 = nullptr;
     ctx->have_data = false;
     ctx->data_capacity = 0;
 }
@@ -232,6 +236,8 @@ DevData dev_data(const tq_ctx *ctx)
     d.rows = ctx->d_rows;
     d.nib = ctx->d_nib;
     d.planes = ctx->d_planes;
+    d.planes3 = ctx->d_planes3;
+    d.runbeg = ctx->d_planes3 + (size_t)ctx->T * (size_t)ctx->plane_cap_W * 3;
     d.pitch = ctx->Sp;
     d.W = ctx->W;
     d.T = (int32_t)ctx->T;
@@ -614,6 +620,8 @@ int tq_set_data(tq_ctx *ctx, const uint8_t *tmparr, int64_t T, int64_t S, const 
     TQ_HIP(ctx, hipMalloc((void **)&ctx->d_rows, (size_t)(T * Sp)));
     TQ_HIP(ctx, hipMalloc((void **)&ctx->d_nib, (size_t)(T * Sp / 2)));
     TQ_HIP(ctx, hipMalloc((void **)&ctx->d_planes, (size_t)(T * W) * sizeof(uint4)));
+    TQ_HIP(ctx, hipMalloc((void **)&ctx->d_planes3, (size_t)(T * W * 3 + W) * sizeof(uint32_t)));
+    ctx->plane_cap_W = W;
     TQ_HIP(ctx, hipMalloc((void **)&d_raw, (size_t)(T * S)));
     hipError_t e = hipMalloc((void **)&d_loc, (size_t)S * sizeof(uint32_t));
     if (e != hipSuccess) {
@@ -625,7 +633,8 @@ int tq_set_data(tq_ctx *ctx, const uint8_t *tmparr, int64_t T, int64_t S, const 
     if (e == hipSuccess) {
         const int64_t n = T * W;
         hipLaunchKernelGGL(tq_prepare_rows, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, d_raw, d_loc, S, Sp,
-                           W, (int32_t)T, ctx->d_rows, ctx->d_nib, ctx->d_planes);
+                           W, (int32_t)T, ctx->d_rows, ctx->d_nib, ctx->d_planes, ctx->d_planes3,
+                           ctx->d_planes3 + (size_t)T * (size_t)W * 3);
         e = hipGetLastError();
         if (e == hipSuccess) e = hipDeviceSynchronize();
     }
@@ -931,6 +940,8 @@ int tq_bootstrap(tq_ctx *ctx, const int64_t *lidxs, int64_t n, uint64_t seed_shu
         TQ_HIP(ctx, hipMalloc((void **)&ctx->d_rows, (size_t)(T * capSp)));
         TQ_HIP(ctx, hipMalloc((void **)&ctx->d_nib, (size_t)(T * capSp / 2)));
         TQ_HIP(ctx, hipMalloc((void **)&ctx->d_planes, (size_t)(T * (capSp / 32)) * sizeof(uint4)));
+        TQ_HIP(ctx, hipMalloc((void **)&ctx->d_planes3, (size_t)(T * (capSp / 32) * 3 + capSp / 32) * sizeof(uint32_t)));
+        ctx->plane_cap_W = capSp / 32;
         ctx->data_capacity = capSp;
     }
     hipLaunchKernelGGL(tq_boot_perm_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, ctx->d_spans,
@@ -938,7 +949,7 @@ int tq_bootstrap(tq_ctx *ctx, const int64_t *lidxs, int64_t n, uint64_t seed_shu
     const int64_t nw = T * W;
     hipLaunchKernelGGL(tq_boot_build_kernel, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, 0, ctx->d_seqarr,
                        ctx->src_S0, src_col, site_locus, S, Sp, W, (int32_t)T, seed_ambig, ctx->d_rows, ctx->d_nib,
-                       ctx->d_planes);
+                       ctx->d_planes, ctx->d_planes3, ctx->d_planes3 + (size_t)T * (size_t)ctx->plane_cap_W * 3);
     TQ_HIP(ctx, hipGetLastError());
     TQ_HIP(ctx, hipDeviceSynchronize());
     ctx->T = T;

@@ -38,16 +38,11 @@ __device__ __forceinline__ void load_tile(TileRegs &r, const DevData &d, const u
 //                    unmasked site precedes i in the same run" obeys
 //                    t(i) = U(i) | (P(i) & t(i-1)), P = ~runbegin, seen(i) = P(i) & t(i-1),
 //                    which is the carry recurrence of the addition (U|P) + U.
+// U = candidate sites (variable among the four taxa, none missing), B = run-begin bits
 template <bool SUB>
-__device__ __forceinline__ uint32_t count_mask(const uint4 &pa, const uint4 &pb, const uint4 &pc, const uint4 &pd,
-                                               int lane, uint32_t &tile_carry)
+__device__ __forceinline__ uint32_t count_from_candidates(uint32_t U, uint32_t B, int lane, uint32_t &tile_carry)
 {
-    const uint32_t M = pa.x | pb.x | pc.x | pd.x;
-    const uint32_t V = (pa.y ^ pb.y) | (pa.z ^ pb.z) | (pa.y ^ pc.y) | (pa.z ^ pc.z) |
-                       (pa.y ^ pd.y) | (pa.z ^ pd.z);
-    const uint32_t U = V & ~M;
     if (!SUB) return U;
-    const uint32_t B = pa.w;
     const uint32_t P = ~B;
     const uint32_t X = U | P;
     const uint32_t sum = X + U;
@@ -69,12 +64,35 @@ __device__ __forceinline__ uint32_t count_mask(const uint4 &pa, const uint4 &pb,
     return U & ~seen;
 }
 
+template <bool SUB>
+__device__ __forceinline__ uint32_t count_mask(const uint4 &pa, const uint4 &pb, const uint4 &pc, const uint4 &pd,
+                                               int lane, uint32_t &tile_carry)
+{
+    const uint32_t M = pa.x | pb.x | pc.x | pd.x;
+    const uint32_t V = (pa.y ^ pb.y) | (pa.z ^ pb.z) | (pa.y ^ pc.y) | (pa.z ^ pc.z) |
+                       (pa.y ^ pd.y) | (pa.z ^ pd.z);
+    return count_from_candidates<SUB>(V & ~M, pa.w, lane, tile_carry);
+}
+
+// the same with the (a,b) part pre-combined by the workgroup: r1 = {p0a, p1a, Ma|Mb, (p0a^p0b)|(p1a^p1b)}
+template <bool SUB>
+__device__ __forceinline__ uint32_t count_mask_shared(const uint4 &r1, uint32_t B, const uint4 &pc, const uint4 &pd,
+                                                      int lane, uint32_t &tile_carry)
+{
+    const uint32_t M = r1.z | pc.x | pd.x;
+    const uint32_t V = r1.w | (r1.x ^ pc.y) | (r1.y ^ pc.z) | (r1.x ^ pd.y) | (r1.y ^ pd.z);
+    return count_from_candidates<SUB>(V & ~M, B, lane, tile_carry);
+}
+
 // METHOD 0: one EXEC-masked ds_add per site slot (32 per step, whatever the density).
 // METHOD 1: the lane parks its 32 pattern bytes in LDS and walks the set bits of C: the number of
 //           ds_add per step is the largest per-lane count in the wave (~10 of 32 in subsample
 //           mode, where at most one site per locus run is counted).
 // METHOD 2 / 3: timing diagnostics (no histogram / no per-step barrier); results are wrong.
-constexpr int PAT_STRIDE = 36;   // bytes per lane in the pattern park (9 dwords: conflict-free b32 stores)
+constexpr int PAT_STRIDE = 36;   // bytes per lane in the pattern park: 9 dwords, so that stores and the byte reads of
+                                 // lanes that sit at the same site index never share a bank (a 32-byte stride with
+                                 // two b128 stores is cheaper in isolation, tools/probe_lds.hip, but 14 % slower here:
+                                 // the first counted sites of neighbouring lanes tend to have similar indices)
 
 // pat[j] holds the 8-bit patterns (a<<6|b<<4|c<<2|d) of sites 4j..4j+3 of this lane, one per byte
 template <int NREP, int METHOD>
@@ -104,23 +122,26 @@ __device__ __forceinline__ void hist_patterns(const uint32_t (&pat)[8], uint32_t
         // would wait for the read it copies)
         uint32_t c = C;
         if (c) {
-            uint32_t b0 = park[__builtin_ctz(c)], b1 = 0;
+            // the loop carries the bin's byte offset (a full 32-bit value: a loop-carried byte would
+            // be re-masked with 0xff at every use)
+            uint8_t *hb = reinterpret_cast<uint8_t *>(hrep);
+            uint32_t o0 = (uint32_t)park[__builtin_ctz(c)] * (4u * NREP), o1 = 0;
             c &= c - 1;
             for (;;) {
                 if (!c) {
-                    __hip_atomic_fetch_add(&hrep[b0 * NREP], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __hip_atomic_fetch_add(reinterpret_cast<uint32_t *>(hb + o0), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     break;
                 }
-                b1 = park[__builtin_ctz(c)];
+                o1 = (uint32_t)park[__builtin_ctz(c)] * (4u * NREP);
                 c &= c - 1;
-                __hip_atomic_fetch_add(&hrep[b0 * NREP], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_add(reinterpret_cast<uint32_t *>(hb + o0), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 if (!c) {
-                    __hip_atomic_fetch_add(&hrep[b1 * NREP], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __hip_atomic_fetch_add(reinterpret_cast<uint32_t *>(hb + o1), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     break;
                 }
-                b0 = park[__builtin_ctz(c)];
+                o0 = (uint32_t)park[__builtin_ctz(c)] * (4u * NREP);
                 c &= c - 1;
-                __hip_atomic_fetch_add(&hrep[b1 * NREP], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_add(reinterpret_cast<uint32_t *>(hb + o1), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
         }
     }
@@ -262,11 +283,11 @@ struct OwnOff {
     uint32_t c, d, pc, pd;
 };
 
-__device__ __forceinline__ void load_own(OwnRegs &r, const uint8_t *nib, const uint8_t *planes3, const OwnOff &o,
-                                         int tile)
+__device__ __forceinline__ void load_own(OwnRegs &r, const uint8_t *nib, const uint8_t *nib4, const uint8_t *planes3,
+                                         const OwnOff &o, int tile)
 {
     const uint32_t tn = (uint32_t)tile * (TILE / 2), tp = (uint32_t)tile * (WAVE * 12);
-    r.c = ld16(nib, o.c + tn);
+    r.c = ld16(nib4, o.c + tn);                  // codes of row c arrive pre-multiplied by 4
     r.d = ld16(nib, o.d + tn);
     r.pc = ld12(planes3, o.pc + tp);
     r.pd = ld12(planes3, o.pd + tp);
@@ -281,7 +302,7 @@ __device__ __forceinline__ void cd_pair(uint32_t cw, uint32_t dw, uint32_t &lo, 
 
 // LDS image of the shared part of one step: abp = pattern partial ((a<<2)+b)<<4 as 2 x 64 uint4
 // panels (sites 0-15 / 16-31 of every lane), then the plane records of a and of b (64 uint4 each)
-constexpr int SHARED_SLOTS = 256;
+constexpr int SHARED_SLOTS = 208;
 
 template <bool SUB, int METHOD, int NW>
 __global__ void __launch_bounds__(NW *WAVE)
@@ -303,15 +324,16 @@ tq_scan_wg_kernel(DevData d, const uint32_t *__restrict__ quartets, const uint32
     const int64_t nblk = (Q + NW - 1) / NW;
     const uint8_t *rows = d.rows;
     const uint8_t *nib = d.nib;
+    const uint8_t *nib4 = d.nib4;
     const uint8_t *planes = reinterpret_cast<const uint8_t *>(d.planes);
     const uint8_t *planes3 = reinterpret_cast<const uint8_t *>(d.planes3);
     const uint8_t *runbeg = reinterpret_cast<const uint8_t *>(d.runbeg);
     const uint32_t pitch = (uint32_t)d.pitch, npitch = pitch / 2, wpitch = (uint32_t)d.W * 16u,
                    w3pitch = (uint32_t)d.W * 12u;
-    // cooperative jobs per step: 0,1 = nibble codes of rows a and b for sites 0-15 / 16-31 of every
-    // lane -> abp panels 0,1; 2 = plane record of a (+ run-begin bits); 3 = plane record of b.
+    // cooperative jobs per step: 0,1 = nibble codes of rows a (x4 copy) and b for sites 0-15 / 16-31
+    // of every lane -> abp panels 0,1; 2 = plane records of a and b (+ run-begin bits) -> r1, B.
     // Wave w takes the jobs j with j % NW == w.
-    constexpr int NJOB = 4, JPW = (NJOB + NW - 1) / NW;        // jobs per wave
+    constexpr int NJOB = 3, JPW = (NJOB + NW - 1) / NW;        // jobs per wave
     __syncthreads();
 
     const int64_t nslot = xcd_chunk > 0 ? 8 * xcd_chunk : nblk;
@@ -356,28 +378,34 @@ tq_scan_wg_kernel(DevData d, const uint32_t *__restrict__ quartets, const uint32
         auto job_of = [=](int i) { return w + i * NW; };                       // wave-uniform
         auto ld8 = [=](const uint8_t *base, uint32_t off) -> uint2 { return *reinterpret_cast<const uint2 *>(base + off); };
         auto fetch_x = [=](int job, int tile) -> uint4 {
-            if (job < 2) {                                   // 8 nibble bytes (16 sites) of a and of b
+            if (job < 2) {                                   // 8 nibble bytes (16 sites) of a (x4) and of b
                 const uint32_t o = (uint32_t)lane * 16u + (uint32_t)job * 8u + (uint32_t)tile * (TILE / 2);
-                const uint2 xa = ld8(nib, la * npitch + o), xb = ld8(nib, lb * npitch + o);
+                const uint2 xa = ld8(nib4, la * npitch + o), xb = ld8(nib, lb * npitch + o);
                 return make_uint4(xa.x, xa.y, xb.x, xb.y);
             }
-            if (job < NJOB) return ld12(planes3, (job == 2 ? la : lb) * w3pitch + (uint32_t)lane * 12u + (uint32_t)tile * (WAVE * 12));
+            if (job == 2) {
+                uint4 r = ld12(planes3, la * w3pitch + (uint32_t)lane * 12u + (uint32_t)tile * (WAVE * 12));
+                r.w = *reinterpret_cast<const uint32_t *>(runbeg + (uint32_t)lane * 4u + (uint32_t)tile * (WAVE * 4));
+                return r;
+            }
             return make_uint4(0, 0, 0, 0);
         };
         auto fetch_y = [=](int job, int tile) -> uint4 {
-            if (job == 2) return make_uint4(*reinterpret_cast<const uint32_t *>(runbeg + (uint32_t)lane * 4u + (uint32_t)tile * (WAVE * 4)), 0, 0, 0);
+            if (job == 2) return ld12(planes3, lb * w3pitch + (uint32_t)lane * 12u + (uint32_t)tile * (WAVE * 12));
             return make_uint4(0, 0, 0, 0);
         };
-        auto combine = [=](int job, uint4 x, uint4 y) -> uint4 {               // what goes into the LDS image
-            if (job == 2) return make_uint4(x.x, x.y, x.z, y.x);
-            if (job > 2) return x;
-            // x = {a.lo8, a.hi8, b.lo8, b.hi8} nibble words -> pattern partial ((a<<2)+b)<<4 of 16 sites
-            const uint32_t m = 0x0F0F0F0Fu;
-            return make_uint4((((x.x & m) << 2) + (x.z & m)) << 4, ((((x.x >> 4) & m) << 2) + ((x.z >> 4) & m)) << 4,
-                              (((x.y & m) << 2) + (x.w & m)) << 4, ((((x.y >> 4) & m) << 2) + ((x.w >> 4) & m)) << 4);
+        // what goes into the LDS image of one step (uint4 slots): abp panels 0-63 / 64-127 =
+        // ((a<<2)+b)<<4 per site byte; r1 128-191 = {p0a, p1a, Ma|Mb, (p0a^p0b)|(p1a^p1b)};
+        // run-begin words 192-207 (64 dwords)
+        auto publish = [=](uint4 *buf, int job, uint4 x, uint4 y) {
+            if (job < 2) {
+                const uint32_t h = 0xF0F0F0F0u, s0 = x.x + x.z, s1 = x.y + x.w;   // a*4+b per nibble
+                buf[job * 64 + lane] = make_uint4((s0 << 4) & h, s0 & h, (s1 << 4) & h, s1 & h);
+            } else if (job == 2) {
+                buf[128 + lane] = make_uint4(x.y, x.z, x.x | y.x, (x.y ^ y.y) | (x.z ^ y.z));
+                reinterpret_cast<uint32_t *>(buf + 192)[lane] = x.w;
+            }
         };
-        // LDS slot of a job's piece: abp panels 0-63 / 64-127, planes a 128-191, planes b 192-255
-        auto slot_of = [=](int job) { return job * 64 + lane; };
 
         // prologue: step 0 into buffer 0
         uint4 sx[JPW], sy[JPW];
@@ -387,22 +415,22 @@ tq_scan_wg_kernel(DevData d, const uint32_t *__restrict__ quartets, const uint32
             sy[i] = fetch_y(job_of(i), 0);
         }
         OwnRegs A, B;
-        load_own(A, nib, planes3, oo, 0);
+        load_own(A, nib, nib4, planes3, oo, 0);
 #pragma unroll
-        for (int i = 0; i < JPW; ++i)
-            if (job_of(i) < NJOB) shared_ab[0][slot_of(job_of(i))] = combine(job_of(i), sx[i], sy[i]);
+        for (int i = 0; i < JPW; ++i) publish(shared_ab[0], job_of(i), sx[i], sy[i]);
         uint32_t tile_carry = 0;
         __syncthreads();
 
         auto step = [&](const OwnRegs &own, int t) {
             if (!work) return;
-            uint4 ab0, ab1, pa, pb;                        // abp panels (sites 0-15, 16-31), plane records
+            uint4 ab0, ab1, r1;                            // abp panels (sites 0-15, 16-31), combined planes
+            uint32_t Bw;                                   // run-begin bits
             if (shares) {
                 const uint4 *buf = shared_ab[t & 1];
                 ab0 = buf[lane];
                 ab1 = buf[64 + lane];
-                pa = buf[128 + lane];
-                pb = buf[192 + lane];
+                r1 = buf[128 + lane];
+                Bw = reinterpret_cast<const uint32_t *>(buf + 192)[lane];
             } else {                                        // group boundary: private rows a and b
                 const uint32_t o0 = q[0] * pitch + (uint32_t)t * TILE + (uint32_t)lane * 16u;
                 const uint32_t o1 = q[1] * pitch + (uint32_t)t * TILE + (uint32_t)lane * 16u;
@@ -412,15 +440,21 @@ tq_scan_wg_kernel(DevData d, const uint32_t *__restrict__ quartets, const uint32
                                  ((a0.w << 2) + b0.w) << 4);
                 ab1 = make_uint4(((a1.x << 2) + b1.x) << 4, ((a1.y << 2) + b1.y) << 4, ((a1.z << 2) + b1.z) << 4,
                                  ((a1.w << 2) + b1.w) << 4);
-                pa = ld16(planes, q[0] * wpitch + (uint32_t)t * (WAVE * 16) + (uint32_t)lane * 16u);
-                pb = ld16(planes, q[1] * wpitch + (uint32_t)t * (WAVE * 16) + (uint32_t)lane * 16u);
+                const uint4 pa = ld16(planes, q[0] * wpitch + (uint32_t)t * (WAVE * 16) + (uint32_t)lane * 16u);
+                const uint4 pb = ld16(planes, q[1] * wpitch + (uint32_t)t * (WAVE * 16) + (uint32_t)lane * 16u);
+                r1 = make_uint4(pa.y, pa.z, pa.x | pb.x, (pa.y ^ pb.y) | (pa.z ^ pb.z));
+                Bw = pa.w;
             }
-            const uint32_t C = count_mask<SUB>(pa, pb, own.pc, own.pd, lane, tile_carry);
-            uint32_t pat[8], lo, hi;
-            cd_pair(own.c.x, own.d.x, lo, hi); pat[0] = ab0.x + lo; pat[1] = ab0.y + hi;
-            cd_pair(own.c.y, own.d.y, lo, hi); pat[2] = ab0.z + lo; pat[3] = ab0.w + hi;
-            cd_pair(own.c.z, own.d.z, lo, hi); pat[4] = ab1.x + lo; pat[5] = ab1.y + hi;
-            cd_pair(own.c.w, own.d.w, lo, hi); pat[6] = ab1.z + lo; pat[7] = ab1.w + hi;
+            const uint32_t C = count_mask_shared<SUB>(r1, Bw, own.pc, own.pd, lane, tile_carry);
+            // own.c holds 4*c, own.d holds d, one site per nibble: their sum is the (c<<2|d) nibble;
+            // the (a<<6|b<<4) byte of the same site sits in the high nibbles of abp
+            const uint32_t m = 0x0F0F0F0Fu;
+            const uint32_t s0 = own.c.x + own.d.x, s1 = own.c.y + own.d.y, s2 = own.c.z + own.d.z, s3 = own.c.w + own.d.w;
+            uint32_t pat[8];
+            pat[0] = (s0 & m) | ab0.x; pat[1] = ((s0 >> 4) & m) | ab0.y;
+            pat[2] = (s1 & m) | ab0.z; pat[3] = ((s1 >> 4) & m) | ab0.w;
+            pat[4] = (s2 & m) | ab1.x; pat[5] = ((s2 >> 4) & m) | ab1.y;
+            pat[6] = (s3 & m) | ab1.z; pat[7] = ((s3 >> 4) & m) | ab1.w;
             hist_patterns<1, METHOD == 3 ? 1 : METHOD>(pat, C, hist, park);
         };
 
@@ -433,13 +467,12 @@ tq_scan_wg_kernel(DevData d, const uint32_t *__restrict__ quartets, const uint32
                     sx[i] = fetch_x(job_of(i), tn);
                     sy[i] = fetch_y(job_of(i), tn);
                 }
-                load_own(B, nib, planes3, oo, tn);
+                load_own(B, nib, nib4, planes3, oo, tn);
                 __builtin_amdgcn_sched_barrier(0);
                 step(A, t);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int i = 0; i < JPW; ++i)
-                    if (job_of(i) < NJOB) shared_ab[(t + 1) & 1][slot_of(job_of(i))] = combine(job_of(i), sx[i], sy[i]);
+                for (int i = 0; i < JPW; ++i) publish(shared_ab[(t + 1) & 1], job_of(i), sx[i], sy[i]);
                 if (METHOD != 3) __syncthreads();      // METHOD 3 = timing diagnostic without the barrier
             }
             if (t + 1 >= d.ntiles) break;
@@ -451,13 +484,12 @@ tq_scan_wg_kernel(DevData d, const uint32_t *__restrict__ quartets, const uint32
                     sx[i] = fetch_x(job_of(i), tn);
                     sy[i] = fetch_y(job_of(i), tn);
                 }
-                load_own(A, nib, planes3, oo, tn);
+                load_own(A, nib, nib4, planes3, oo, tn);
                 __builtin_amdgcn_sched_barrier(0);
                 step(B, t + 1);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int i = 0; i < JPW; ++i)
-                    if (job_of(i) < NJOB) shared_ab[t & 1][slot_of(job_of(i))] = combine(job_of(i), sx[i], sy[i]);
+                for (int i = 0; i < JPW; ++i) publish(shared_ab[t & 1], job_of(i), sx[i], sy[i]);
                 if (METHOD != 3) __syncthreads();
             }
         }

@@ -235,6 +235,7 @@ DevData dev_data(const tq_ctx *ctx)
     DevData d;
     d.rows = ctx->d_rows;
     d.nib = ctx->d_nib;
+    d.nib4 = ctx->d_nib + (size_t)ctx->T * (size_t)ctx->data_capacity / 2;
     d.planes = ctx->d_planes;
     d.planes3 = ctx->d_planes3;
     d.runbeg = ctx->d_planes3 + (size_t)ctx->T * (size_t)ctx->plane_cap_W * 3;
@@ -618,7 +619,7 @@ int tq_set_data(tq_ctx *ctx, const uint8_t *tmparr, int64_t T, int64_t S, const 
     uint8_t *d_raw = nullptr;
     uint32_t *d_loc = nullptr;
     TQ_HIP(ctx, hipMalloc((void **)&ctx->d_rows, (size_t)(T * Sp)));
-    TQ_HIP(ctx, hipMalloc((void **)&ctx->d_nib, (size_t)(T * Sp / 2)));
+    TQ_HIP(ctx, hipMalloc((void **)&ctx->d_nib, (size_t)(T * Sp)));             // nib, then nib4
     TQ_HIP(ctx, hipMalloc((void **)&ctx->d_planes, (size_t)(T * W) * sizeof(uint4)));
     TQ_HIP(ctx, hipMalloc((void **)&ctx->d_planes3, (size_t)(T * W * 3 + W) * sizeof(uint32_t)));
     ctx->plane_cap_W = W;
@@ -633,7 +634,8 @@ int tq_set_data(tq_ctx *ctx, const uint8_t *tmparr, int64_t T, int64_t S, const 
     if (e == hipSuccess) {
         const int64_t n = T * W;
         hipLaunchKernelGGL(tq_prepare_rows, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, d_raw, d_loc, S, Sp,
-                           W, (int32_t)T, ctx->d_rows, ctx->d_nib, ctx->d_planes, ctx->d_planes3,
+                           W, (int32_t)T, ctx->d_rows, ctx->d_nib, ctx->d_nib + (size_t)(T * Sp / 2), ctx->d_planes,
+                           ctx->d_planes3,
                            ctx->d_planes3 + (size_t)T * (size_t)W * 3);
         e = hipGetLastError();
         if (e == hipSuccess) e = hipDeviceSynchronize();
@@ -938,7 +940,7 @@ int tq_bootstrap(tq_ctx *ctx, const int64_t *lidxs, int64_t n, uint64_t seed_shu
         free_data(ctx);
         const int64_t capSp = (int64_t)align_up((size_t)(Sp + Sp / 8), TILE);   // head-room: replicate lengths vary
         TQ_HIP(ctx, hipMalloc((void **)&ctx->d_rows, (size_t)(T * capSp)));
-        TQ_HIP(ctx, hipMalloc((void **)&ctx->d_nib, (size_t)(T * capSp / 2)));
+        TQ_HIP(ctx, hipMalloc((void **)&ctx->d_nib, (size_t)(T * capSp)));      // nib, then nib4
         TQ_HIP(ctx, hipMalloc((void **)&ctx->d_planes, (size_t)(T * (capSp / 32)) * sizeof(uint4)));
         TQ_HIP(ctx, hipMalloc((void **)&ctx->d_planes3, (size_t)(T * (capSp / 32) * 3 + capSp / 32) * sizeof(uint32_t)));
         ctx->plane_cap_W = capSp / 32;
@@ -949,6 +951,7 @@ int tq_bootstrap(tq_ctx *ctx, const int64_t *lidxs, int64_t n, uint64_t seed_shu
     const int64_t nw = T * W;
     hipLaunchKernelGGL(tq_boot_build_kernel, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, 0, ctx->d_seqarr,
                        ctx->src_S0, src_col, site_locus, S, Sp, W, (int32_t)T, seed_ambig, ctx->d_rows, ctx->d_nib,
+                       ctx->d_nib + (size_t)T * (size_t)ctx->data_capacity / 2,
                        ctx->d_planes, ctx->d_planes3, ctx->d_planes3 + (size_t)T * (size_t)ctx->plane_cap_W * 3);
     TQ_HIP(ctx, hipGetLastError());
     TQ_HIP(ctx, hipDeviceSynchronize());

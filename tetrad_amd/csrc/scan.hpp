@@ -122,26 +122,25 @@ __device__ __forceinline__ void hist_patterns(const uint32_t (&pat)[8], uint32_t
         // would wait for the read it copies)
         uint32_t c = C;
         if (c) {
-            // the loop carries the bin's byte offset (a full 32-bit value: a loop-carried byte would
-            // be re-masked with 0xff at every use)
-            uint8_t *hb = reinterpret_cast<uint8_t *>(hrep);
-            uint32_t o0 = (uint32_t)park[__builtin_ctz(c)] * (4u * NREP), o1 = 0;
+            // the loop carries the bin's address (a full 32-bit value: a loop-carried byte would be
+            // re-masked with 0xff at every use)
+            uint32_t *p0 = hrep + (uint32_t)park[__builtin_ctz(c)] * NREP, *p1 = nullptr;
             c &= c - 1;
             for (;;) {
                 if (!c) {
-                    __hip_atomic_fetch_add(reinterpret_cast<uint32_t *>(hb + o0), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __hip_atomic_fetch_add(p0, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     break;
                 }
-                o1 = (uint32_t)park[__builtin_ctz(c)] * (4u * NREP);
+                p1 = hrep + (uint32_t)park[__builtin_ctz(c)] * NREP;
                 c &= c - 1;
-                __hip_atomic_fetch_add(reinterpret_cast<uint32_t *>(hb + o0), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_add(p0, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 if (!c) {
-                    __hip_atomic_fetch_add(reinterpret_cast<uint32_t *>(hb + o1), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __hip_atomic_fetch_add(p1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     break;
                 }
-                o0 = (uint32_t)park[__builtin_ctz(c)] * (4u * NREP);
+                p0 = hrep + (uint32_t)park[__builtin_ctz(c)] * NREP;
                 c &= c - 1;
-                __hip_atomic_fetch_add(reinterpret_cast<uint32_t *>(hb + o1), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_add(p1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
         }
     }
@@ -269,6 +268,14 @@ struct OwnRegs {
 __device__ __forceinline__ uint4 ld16(const uint8_t *base, uint32_t off)
 {
     return *reinterpret_cast<const uint4 *>(base + off);
+}
+
+// (a & m) | c in one instruction; m must sit in an SGPR (the compiler emits v_and + v_or otherwise)
+__device__ __forceinline__ uint32_t and_or(uint32_t a, uint32_t m, uint32_t c)
+{
+    uint32_t r;
+    asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(m), "v"(c));
+    return r;
 }
 
 // 12-byte load (one compact plane record {miss, p0, p1}); .w of the result is 0
@@ -448,13 +455,16 @@ tq_scan_wg_kernel(DevData d, const uint32_t *__restrict__ quartets, const uint32
             const uint32_t C = count_mask_shared<SUB>(r1, Bw, own.pc, own.pd, lane, tile_carry);
             // own.c holds 4*c, own.d holds d, one site per nibble: their sum is the (c<<2|d) nibble;
             // the (a<<6|b<<4) byte of the same site sits in the high nibbles of abp
-            const uint32_t m = 0x0F0F0F0Fu;
+            // (the mask lives in an SGPR so that (s & m) | ab is one v_and_or_b32; as a literal it
+            // cannot be encoded in a three-operand instruction and costs a second one)
+            uint32_t m;
+            asm("s_mov_b32 %0, 0x0f0f0f0f" : "=s"(m));
             const uint32_t s0 = own.c.x + own.d.x, s1 = own.c.y + own.d.y, s2 = own.c.z + own.d.z, s3 = own.c.w + own.d.w;
             uint32_t pat[8];
-            pat[0] = (s0 & m) | ab0.x; pat[1] = ((s0 >> 4) & m) | ab0.y;
-            pat[2] = (s1 & m) | ab0.z; pat[3] = ((s1 >> 4) & m) | ab0.w;
-            pat[4] = (s2 & m) | ab1.x; pat[5] = ((s2 >> 4) & m) | ab1.y;
-            pat[6] = (s3 & m) | ab1.z; pat[7] = ((s3 >> 4) & m) | ab1.w;
+            pat[0] = and_or(s0, m, ab0.x); pat[1] = and_or(s0 >> 4, m, ab0.y);
+            pat[2] = and_or(s1, m, ab0.z); pat[3] = and_or(s1 >> 4, m, ab0.w);
+            pat[4] = and_or(s2, m, ab1.x); pat[5] = and_or(s2 >> 4, m, ab1.y);
+            pat[6] = and_or(s3, m, ab1.z); pat[7] = and_or(s3 >> 4, m, ab1.w);
             hist_patterns<1, METHOD == 3 ? 1 : METHOD>(pat, C, hist, park);
         };
 

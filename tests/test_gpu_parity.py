@@ -373,3 +373,19 @@ def test_many_taxa_small_sites(engine, oracle):
         assert_close(rscor, o_rscor, smax[:, None], "scores")
         ok = ((flags | o["flags"]) & 3) == 0
         np.testing.assert_array_equal(rstat[ok, 0], o_rstat[ok, 0])
+
+
+def test_taxa_beyond_three_field_sort_key(engine, oracle):
+    """T = 1700: T^3 no longer fits the 32-bit sort key, so the order falls back to (a,b) only."""
+    from tetrad_amd import synth
+    tmparr, tmpmap = synth.simulate_tmparr(1700, 300, seed=17, p=0.02, missing=0.1)
+    q = synth.random_quartets(1700, 1500, seed=3)
+    engine.set_data(tmparr, tmpmap)
+    for sub in (True, False):
+        rstat, rscor, flags = engine.resolve(q, sub)
+        _, o_rstat, o_rscor, o = oracle.new_infer_resolved_quartets(tmparr, tmpmap, q, sub, debug=True)
+        np.testing.assert_array_equal(rstat[:, 1], o_rstat[:, 1])
+        smax = np.maximum(o["svds"].max(axis=(1, 2)), 1e-300)
+        assert_close(rscor, o_rscor, smax[:, None], "scores")
+        ok = ((flags | o["flags"]) & 3) == 0
+        np.testing.assert_array_equal(rstat[ok, 0], o_rstat[ok, 0])

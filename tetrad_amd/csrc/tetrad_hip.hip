@@ -78,6 +78,8 @@ struct tq_ctx {
     size_t boot_tmp_bytes = 0;
     // scratch for the host-buffer API
     void *d_scratch = nullptr;
+    void *h_stage = nullptr;        // pinned staging for small host-buffer calls
+    size_t stage_bytes = 0;
     size_t scratch_bytes = 0;
     // count-matrix slab between the two kernels: u32 [batch][256]
     uint32_t *d_cm = nullptr;
@@ -180,6 +182,17 @@ int ensure_scratch(tq_ctx *ctx, size_t bytes)
     return TQ_OK;
 }
 
+int ensure_stage(tq_ctx *ctx, size_t bytes)
+{
+    if (bytes <= ctx->stage_bytes) return TQ_OK;
+    if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
+    ctx->h_stage = nullptr;
+    ctx->stage_bytes = 0;
+    TQ_HIP(ctx, hipHostMalloc(&ctx->h_stage, bytes, hipHostMallocDefault));
+    ctx->stage_bytes = bytes;
+    return TQ_OK;
+}
+
 int ensure_cm(tq_ctx *ctx, int64_t quartets)
 {
     if (quartets <= ctx->cm_quartets) return TQ_OK;
@@ -245,6 +258,8 @@ DevData dev_data(const tq_ctx *ctx)
     d.ntiles = (int32_t)(ctx->Sp / TILE);
     return d;
 }
+
+constexpr size_t STAGE_LIMIT = 2u << 20;     // bytes of quartets + results that go through pinned staging
 
 template <typename K>
 int grid_for(tq_ctx *ctx, K kern, int64_t items, int64_t *grid, int wpc_kernel = 0)
@@ -558,6 +573,7 @@ void tq_destroy(tq_ctx *ctx)
     free_data(ctx);
     free_source(ctx);
     if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
+    if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
     if (ctx->d_cm) (void)hipFree(ctx->d_cm);
     if (ctx->d_sort) (void)hipFree(ctx->d_sort);
     if (ctx->d_sort_tmp) (void)hipFree(ctx->d_sort_tmp);
@@ -728,7 +744,19 @@ int tq_resolve_debug(tq_ctx *ctx, const uint32_t *quartets, int64_t Q, int subsa
     int rc = ensure_scratch(ctx, total);
     if (rc) return rc;
     char *base = (char *)ctx->d_scratch;
-    TQ_HIP(ctx, hipMemcpy(base + o_q, quartets, (size_t)Q * 16, hipMemcpyHostToDevice));
+    // Small calls (the reference's distributor hands out chunks of a few thousand quartets,
+    // run_inference.py:73-96) are dominated by the number of blocking HIP calls: they go through one
+    // pinned staging buffer -- one H2D, one D2H for the three result arrays -- instead of four pageable
+    // copies.  Large calls keep the direct copies (an extra host pass over 49 B/quartet costs more).
+    const bool staged = !debug && o_cm <= STAGE_LIMIT;
+    if (staged) {
+        rc = ensure_stage(ctx, o_cm);
+        if (rc) return rc;
+        memcpy(ctx->h_stage, quartets, (size_t)Q * 16);
+        TQ_HIP(ctx, hipMemcpyAsync(base + o_q, ctx->h_stage, (size_t)Q * 16, hipMemcpyHostToDevice, nullptr));
+    } else {
+        TQ_HIP(ctx, hipMemcpy(base + o_q, quartets, (size_t)Q * 16, hipMemcpyHostToDevice));
+    }
     OutPtrs out;
     out.rstat = (uint32_t *)(base + o_rstat);
     out.rscor = (double *)(base + o_rscor);
@@ -738,6 +766,15 @@ int tq_resolve_debug(tq_ctx *ctx, const uint32_t *quartets, int64_t Q, int subsa
     out.ranks = ranks ? (int32_t *)(base + o_rk) : nullptr;
     rc = launch(ctx, (const uint32_t *)(base + o_q), Q, subsample, debug, out, nullptr);
     if (rc) return rc;
+    if (staged) {
+        TQ_HIP(ctx, hipMemcpyAsync((char *)ctx->h_stage + o_rstat, base + o_rstat, o_cm - o_rstat, hipMemcpyDeviceToHost,
+                                   nullptr));
+        TQ_HIP(ctx, hipStreamSynchronize(nullptr));
+        memcpy(rstat, (char *)ctx->h_stage + o_rstat, (size_t)Q * 8);
+        memcpy(rscor, (char *)ctx->h_stage + o_rscor, (size_t)Q * 24);
+        if (flags) memcpy(flags, (char *)ctx->h_stage + o_flags, (size_t)Q);
+        return TQ_OK;
+    }
     TQ_HIP(ctx, hipDeviceSynchronize());
     TQ_HIP(ctx, hipMemcpy(rstat, out.rstat, (size_t)Q * 8, hipMemcpyDeviceToHost));
     TQ_HIP(ctx, hipMemcpy(rscor, out.rscor, (size_t)Q * 24, hipMemcpyDeviceToHost));

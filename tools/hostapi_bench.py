@@ -17,3 +17,12 @@ ts=[]
 for _ in range(5):
     t0=time.perf_counter(); r=eng.resolve(q, True); ts.append(time.perf_counter()-t0)
 print(f"tq_resolve, {Q} quartets: {min(ts)*1e3:7.2f} ms  {Q/min(ts)/1e6:6.2f} Mq/s (PCIe inclusive)")
+# chunk sizes the reference's distributor produces (run_inference.py:73-96: nquartets // (breaks * ncores))
+for n in (1_000, 8_000, 31_250, 125_000):
+    eng.resolve(q[:n], True)
+    reps = max(3, 200_000 // n)
+    t0 = time.perf_counter()
+    for i in range(reps):
+        eng.resolve(q[i * n % (Q - n):][:n], True)
+    dt = (time.perf_counter() - t0) / reps
+    print(f"tq_resolve, chunk {n:7d}: {dt*1e3:7.3f} ms per call  {n/dt/1e6:6.2f} Mq/s")

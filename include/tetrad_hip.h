@@ -158,6 +158,23 @@ int tq_set_option(tq_ctx *ctx, const char *name, int64_t value);
  * n = quartets of the last batch.  No reference counterpart.                                   */
 int tq_debug_fetch(tq_ctx *ctx, int which, void *dst, int64_t bytes);
 
+/* Text for the consumers right after the hot path (host code, no device involved).
+ * tq_format_tsv writes the rows the reference appends to <name>.quartets_<rep>.tsv
+ *   (run_inference.py:233-234: pd.concat([rqrts, rscor, rstat], axis=1).to_csv(sep="\t",
+ *   float_format='%.6f', index=False, header=False)): "a\tb\tc\td\ts0\ts1\ts2\ttopo\tnsnps\n".
+ * tq_format_qmc writes the wQMC input lines "a,b|c,d:weight\n" of iter_qmc_formatted
+ *   (run_inference.py:254-305) for the rows that pass min_snps (:258,:275) and min_ratio (:300), with the
+ *   weight strategies 0..3 (:280-297) computed, as the reference does, from the scores as they read
+ *   back from the TSV (rounded to 6 decimals); *n_lines = lines written.  The reference then shuffles
+ *   the file with `shuf` (:326-327); that is left to the caller.
+ * Both return TQ_OK with *written = bytes produced (no terminating 0), TQ_ERR_OOM with *written = a
+ * buffer size that is sufficient when `cap` was too small, TQ_ERR_INVALID_ARG otherwise.            */
+int tq_format_tsv(const uint32_t *quartets, const uint32_t *rstat, const double *rscor, int64_t Q,
+                  char *out, int64_t cap, int64_t *written);
+int tq_format_qmc(const uint32_t *quartets, const uint32_t *rstat, const double *rscor, int64_t Q,
+                  int weights, int64_t min_snps, double min_ratio, char *out, int64_t cap,
+                  int64_t *written, int64_t *n_lines);
+
 /* Device facts used by bench.py: writes CU count, wave slots used by the resolve
  * kernel per CU and the padded row pitch in bytes.                                 */
 int tq_device_info(tq_ctx *ctx, int32_t *num_cu, int32_t *waves_per_cu, int64_t *row_pitch);

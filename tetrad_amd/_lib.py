@@ -30,6 +30,7 @@ SYMBOLS = [
     "tq_set_source", "tq_bootstrap", "tq_get_data", "tq_data_shape",
     "tq_resolve_dev", "tq_resolve_range_dev", "tq_unrank_dev", "tq_resolve_debug",
     "tq_timing_enable", "tq_timing_read", "tq_timing_read_split", "tq_set_option", "tq_device_info", "tq_debug_fetch",
+    "tq_format_tsv", "tq_format_qmc",
 ]
 
 
@@ -112,6 +113,10 @@ def load() -> ctypes.CDLL:
     lib.tq_debug_fetch.restype = i32
     lib.tq_set_option.argtypes = [vp, c.c_char_p, i64]
     lib.tq_set_option.restype = i32
+    lib.tq_format_tsv.argtypes = [vp, vp, vp, i64, vp, i64, c.POINTER(i64)]
+    lib.tq_format_tsv.restype = i32
+    lib.tq_format_qmc.argtypes = [vp, vp, vp, i64, i32, i64, c.c_double, vp, i64, c.POINTER(i64), c.POINTER(i64)]
+    lib.tq_format_qmc.restype = i32
     lib.tq_device_info.argtypes = [vp, c.POINTER(c.c_int32), c.POINTER(c.c_int32), c.POINTER(i64)]
     lib.tq_device_info.restype = i32
     _lib = lib

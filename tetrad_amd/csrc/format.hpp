@@ -1,0 +1,132 @@
+// format.hpp -- host-side text producers for the consumers right after the hot path
+// (SURVEY.md section 8 row f3): the 9-column quartets TSV (run_inference.py:233-234) and the wQMC
+// input lines (run_inference.py:254-305).  No device code; part of the single translation unit
+// tetrad_hip.hip (included inside its anonymous namespace).
+#pragma once
+
+// Decimal text of x with `dec` (<= 9) digits after the point, identical to printf("%.<dec>f").
+// Fast path: round x * 10^dec to the nearest integer; when the product is so close to a tie that its
+// own rounding error could decide the direction, or x is outside the comfortable range, snprintf
+// (exact decimal expansion of the binary value) takes over.
+inline char *put_fixed(char *p, double x, int dec)
+{
+    static const double P10[10] = {1e0, 1e1, 1e2, 1e3, 1e4, 1e5, 1e6, 1e7, 1e8, 1e9};
+    if (x >= 0.0 && x < 4.0e9 && dec >= 0 && dec <= 9) {
+        const double scaled = x * P10[dec];                 // relative error 2^-53: below 5e-7 absolute
+        const double fl = std::floor(scaled);               // while scaled < 2^32
+        const double frac = scaled - fl;
+        if (std::fabs(frac - 0.5) > 2e-6 && scaled < 4.0e9) {
+            uint64_t v = (uint64_t)fl + (frac > 0.5 ? 1u : 0u);
+            char tmp[40];
+            int n = 0;
+            for (int i = 0; i < dec; ++i) {
+                tmp[n++] = (char)('0' + v % 10);
+                v /= 10;
+            }
+            if (dec) tmp[n++] = '.';
+            do {
+                tmp[n++] = (char)('0' + v % 10);
+                v /= 10;
+            } while (v);
+            while (n) *p++ = tmp[--n];
+            return p;
+        }
+    }
+    return p + snprintf(p, 400, "%.*f", dec, x);
+}
+
+inline char *put_u32(char *p, uint32_t v)
+{
+    char tmp[12];
+    int n = 0;
+    do {
+        tmp[n++] = (char)('0' + v % 10);
+        v /= 10;
+    } while (v);
+    while (n) *p++ = tmp[--n];
+    return p;
+}
+
+constexpr int64_t TSV_MAX_LINE = 4 * 11 + 3 * 330 + 2 * 11;     // generous upper bound per row (f64 max ~ 1e308)
+constexpr int64_t QMC_MAX_LINE = 4 * 11 + 330;
+
+// rows "a\tb\tc\td\tscore0\tscore1\tscore2\ttopo\tnsnps\n"; returns bytes written, or -(bytes the
+// buffer must hold) when `cap` is too small for the worst case
+inline int64_t format_tsv(const uint32_t *quartets, const uint32_t *rstat, const double *rscor, int64_t Q, char *out,
+                          int64_t cap)
+{
+    char *p = out;
+    char *const end = out + cap;
+    for (int64_t i = 0; i < Q; ++i) {
+        if (end - p < TSV_MAX_LINE) {
+            // slow exact sizing of what is left, so that the caller can retry with the right size
+            int64_t need = p - out;
+            char line[TSV_MAX_LINE];
+            for (int64_t j = i; j < Q; ++j) {
+                char *q = line;
+                for (int k = 0; k < 4; ++k) { q = put_u32(q, quartets[j * 4 + k]); *q++ = '\t'; }
+                for (int k = 0; k < 3; ++k) { q = put_fixed(q, rscor[j * 3 + k], 6); *q++ = '\t'; }
+                q = put_u32(q, rstat[j * 2]); *q++ = '\t';
+                q = put_u32(q, rstat[j * 2 + 1]); *q++ = '\n';
+                need += q - line;
+            }
+            return -(need + TSV_MAX_LINE);
+        }
+        for (int k = 0; k < 4; ++k) { p = put_u32(p, quartets[i * 4 + k]); *p++ = '\t'; }
+        for (int k = 0; k < 3; ++k) { p = put_fixed(p, rscor[i * 3 + k], 6); *p++ = '\t'; }
+        p = put_u32(p, rstat[i * 2]); *p++ = '\t';
+        p = put_u32(p, rstat[i * 2 + 1]); *p++ = '\n';
+    }
+    return p - out;
+}
+
+// the value the reference reads back from the TSV: the score rounded to 6 decimals as text
+inline double reread6(double x)
+{
+    char buf[400];
+    char *e = put_fixed(buf, x, 6);
+    *e = 0;
+    return strtod(buf, nullptr);
+}
+
+// "a,b|c,d:weight\n" lines (run_inference.py:264-305) for the rows that pass the two filters;
+// returns bytes written (or -needed), *n_lines = lines produced
+inline int64_t format_qmc(const uint32_t *quartets, const uint32_t *rstat, const double *rscor, int64_t Q, int weights,
+                          int64_t min_snps, double min_ratio, char *out, int64_t cap, int64_t *n_lines)
+{
+    if (min_snps < 1) min_snps = 1;                                   // :258
+    char *p = out;
+    char *const end = out + cap;
+    int64_t lines = 0;
+    for (int64_t i = 0; i < Q; ++i) {
+        if (end - p < QMC_MAX_LINE) return -((p - out) + (Q - i) * QMC_MAX_LINE);
+        const uint32_t *q = quartets + i * 4;
+        const uint32_t order = rstat[i * 2], nsnps = rstat[i * 2 + 1];
+        if ((int64_t)nsnps < min_snps) continue;                      // :275
+        double weight = 1.0, ratio = 1.0;
+        if (weights) {                                                // :284-297
+            double s[3] = {reread6(rscor[i * 3]), reread6(rscor[i * 3 + 1]), reread6(rscor[i * 3 + 2])};
+            if (s[0] > s[1]) std::swap(s[0], s[1]);
+            if (s[1] > s[2]) std::swap(s[1], s[2]);
+            if (s[0] > s[1]) std::swap(s[0], s[1]);
+            const double smean = (s[1] + s[2]) / 2.0;                 // numpy mean of two values
+            const double smin = s[0];
+            ratio = smin == 0.0 ? 1.0 : smean / smin;
+            if (weights == 1) weight = smean;
+            else if (weights == 2) weight = ratio;
+            else weight = 1.0 - smin / ((s[0] + s[1]) + s[2]);        // numpy sum, left to right
+        }
+        if (ratio < min_ratio) continue;                              // :300
+        uint32_t a = q[0], b = q[1], c = q[2], d = q[3];
+        if (order == 1) { b = q[2]; c = q[1]; }                       // a,c|b,d
+        else if (order == 2) { b = q[3]; c = q[1]; d = q[2]; }        // a,d|b,c
+        p = put_u32(p, a); *p++ = ',';
+        p = put_u32(p, b); *p++ = '|';
+        p = put_u32(p, c); *p++ = ',';
+        p = put_u32(p, d); *p++ = ':';
+        p = put_fixed(p, weight, 5); *p++ = '\n';
+        ++lines;
+    }
+    if (n_lines) *n_lines = lines;
+    return p - out;
+}

@@ -28,7 +28,10 @@
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
 
+#include <cmath>
 #include <cstdarg>
+#include <cstdlib>
+#include <utility>
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
@@ -47,6 +50,7 @@ namespace {
 #include "jacobi.hpp"
 #include "hqr.hpp"
 #include "bootstrap.hpp"
+#include "format.hpp"
 
 }  // namespace
 
@@ -1055,6 +1059,26 @@ int tq_debug_fetch(tq_ctx *ctx, int which, void *dst, int64_t bytes)
     TQ_HIP(ctx, hipDeviceSynchronize());
     TQ_HIP(ctx, hipMemcpy(dst, src, (size_t)bytes, hipMemcpyDeviceToHost));
     return TQ_OK;
+}
+
+int tq_format_tsv(const uint32_t *quartets, const uint32_t *rstat, const double *rscor, int64_t Q, char *out,
+                  int64_t cap, int64_t *written)
+{
+    if (Q < 0 || cap < 0 || !written || (Q > 0 && (!quartets || !rstat || !rscor || !out))) return TQ_ERR_INVALID_ARG;
+    const int64_t n = format_tsv(quartets, rstat, rscor, Q, out, cap);
+    *written = n < 0 ? -n : n;
+    return n < 0 ? TQ_ERR_OOM : TQ_OK;
+}
+
+int tq_format_qmc(const uint32_t *quartets, const uint32_t *rstat, const double *rscor, int64_t Q, int weights,
+                  int64_t min_snps, double min_ratio, char *out, int64_t cap, int64_t *written, int64_t *n_lines)
+{
+    if (Q < 0 || cap < 0 || !written || weights < 0 || weights > 3 ||
+        (Q > 0 && (!quartets || !rstat || !rscor || !out)))
+        return TQ_ERR_INVALID_ARG;
+    const int64_t n = format_qmc(quartets, rstat, rscor, Q, weights, min_snps, min_ratio, out, cap, n_lines);
+    *written = n < 0 ? -n : n;
+    return n < 0 ? TQ_ERR_OOM : TQ_OK;
 }
 
 int tq_device_info(tq_ctx *ctx, int32_t *num_cu, int32_t *waves_per_cu, int64_t *row_pitch)

@@ -126,15 +126,37 @@ def resolve_sharded(tmparr, tmpmap, quartets, subsample_snps: bool = True, *, gr
 # --------------------------------------------------------------------------------------------
 # consumer of the triple: the quartets TSV (run_inference.py:232-244)
 # --------------------------------------------------------------------------------------------
+def format_tsv_bytes(rqrts: np.ndarray, rscor: np.ndarray, rstat: np.ndarray) -> bytes:
+    """The rows of the quartets TSV as bytes (native formatter of the C ABI: `tq_format_tsv`)."""
+    import ctypes
+    from . import _lib
+    lib = _lib.load()
+    q = np.ascontiguousarray(rqrts, dtype=np.uint32).reshape(-1, 4)
+    st = np.ascontiguousarray(rstat, dtype=np.uint32).reshape(-1, 2)
+    sc = np.ascontiguousarray(rscor, dtype=np.float64).reshape(-1, 3)
+    n = q.shape[0]
+    if st.shape[0] != n or sc.shape[0] != n:
+        raise ValueError("rqrts, rscor and rstat must have the same number of rows")
+    cap = 96 * n + 4096
+    written = ctypes.c_int64()
+    for _ in range(2):
+        buf = np.empty(cap, dtype=np.uint8)
+        rc = lib.tq_format_tsv(q.ctypes.data, st.ctypes.data, sc.ctypes.data, n, buf.ctypes.data, cap,
+                               ctypes.byref(written))
+        if rc == 0:
+            return buf[:written.value].tobytes()
+        if rc != -6:                                               # TQ_ERR_OOM carries the size to retry with
+            raise _lib.TetradHipError(rc, "tq_format_tsv")
+        cap = written.value
+    raise _lib.TetradHipError(rc, "tq_format_tsv: buffer sizing failed")
+
+
 def format_tsv(rqrts: np.ndarray, rscor: np.ndarray, rstat: np.ndarray) -> str:
     """Same text as the reference's
     ``pd.concat([DataFrame(rqrts), DataFrame(rscor), DataFrame(rstat)], axis=1)
       .to_csv(sep="\\t", float_format='%.6f', index=False, header=False)``
     (run_inference.py:233-234): 9 columns  a b c d score0 score1 score2 topo nsnps."""
-    rows = []
-    for q, s, t in zip(rqrts.tolist(), rscor.tolist(), rstat.tolist()):
-        rows.append("%d\t%d\t%d\t%d\t%.6f\t%.6f\t%.6f\t%d\t%d\n" % (*q, *s, *t))
-    return "".join(rows)
+    return format_tsv_bytes(rqrts, rscor, rstat).decode("ascii")
 
 
 def distributor(database_file: Path, qrts_file: Path, nsamples: int, qiter: Iterable, subsample_snps: bool,
@@ -155,6 +177,6 @@ def distributor(database_file: Path, qrts_file: Path, nsamples: int, qiter: Iter
         rqrts, rstat, rscor, _ = resolve_sharded(tmparr, tmpmap, qrts, subsample_snps, group=group,
                                                  compute=compute)
         if rank == 0:
-            with open(qrts_file, "a") as out:                      # :240-244
-                out.write(format_tsv(rqrts, rscor, rstat))
+            with open(qrts_file, "ab") as out:                     # :240-244
+                out.write(format_tsv_bytes(rqrts, rscor, rstat))
     return qrts_file

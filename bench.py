@@ -76,7 +76,15 @@ def cpu_baseline(tmparr, tmpmap, quartets, sub, gpu_rstat, gpu_rscor, budget_s=1
         topology_equal=bool(np.array_equal(rstat[:, 0], gpu_rstat[:n, 0])),
         score_max_rel_err=float(np.max(np.abs(rscor - gpu_rscor[:n]) / np.abs(rscor))),
     )
-    return dict(value=n / wall, unit="quartets/s", cores=cores, kind="port",
+    model = ""
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                model = ln.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return dict(value=n / wall, unit="quartets/s", cores=cores, cpu_model=model, kind="port",
                 sample=f"first {n} quartets of the same batch, {cores} processes x 1 thread, "
                        f"oracle.new_infer_resolved_quartets (C count loop + numpy.linalg svd/matrix_rank)",
                 per_core=per_core), parity
@@ -205,6 +213,22 @@ def main():
     eng.resolve(quartets, sub)
     pcie_inclusive = Q / (time.perf_counter() - t1)
 
+    # device-to-device copy rate of this GPU (what "8 TB/s" means in practice here; SURVEY 8d asks
+    # for the vendor figure and a measured one side by side): 1 GiB read + 1 GiB written per copy
+    hbm_copy = None
+    if rank == 0:
+        src = torch.empty(1 << 30, dtype=torch.uint8, device=dev)
+        dst = torch.empty_like(src)
+        dst.copy_(src)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            dst.copy_(src)
+        e1.record()
+        torch.cuda.synchronize()
+        hbm_copy = 5 * 2 * (1 << 30) / (e0.elapsed_time(e1) / 1e3) / 1e9
+        del src, dst
+
     last = (counter[0] - 1) % nbuf
     rstat = d_rstats[last].cpu().numpy().astype(np.uint32)
     rscor = d_rscors[last].cpu().numpy()
@@ -231,6 +255,7 @@ def main():
                        "subsample_snps": sub, "parallelism": f"quartet-sharded x{world} + all-gather"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "hbm_copy_measured_GBs": hbm_copy,
                          "kernel": "one pass of the hot path: tq_scan_wg_kernel (+ordering) then tq_bidiag/tq_bdsqr/tq_score",
                          "kernel_ms": kernel_ms / max(1, launches),
                          "scan_stage_ms": scan_ms / max(1, launches),

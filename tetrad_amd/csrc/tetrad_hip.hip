@@ -101,6 +101,7 @@ struct tq_ctx {
     // software pipeline across sub-batches: scan of sub-batch i+1 runs on a second stream beside the
     // singular-value stage of sub-batch i (0 = off: one stage after the other on the caller's stream)
     int64_t overlap = 0;            // sub-batch size in quartets
+    bool input_sorted = false;      // set by the host-buffer entry points when the quartets already are in key order
     int xcd_remap = 1;              // 1: scan workgroups of one XCD take a contiguous part of the sorted order
     int svd_wpc = 0;                // blocks per CU of the bidiag / bdsqr grids (0 = one pass per block)
     int ov_scan_wgs = 1;            // scan workgroups per CU while overlapping
@@ -230,7 +231,7 @@ int ensure_cm(tq_ctx *ctx, int64_t quartets)
 int make_order(tq_ctx *ctx, const uint32_t *dq, int64_t n, hipStream_t stream, const uint32_t **order)
 {
     *order = nullptr;
-    if (!ctx->order || n < 1024 || ctx->T > 65535) return TQ_OK;
+    if (!ctx->order || n < 1024 || ctx->T > 65535 || ctx->input_sorted) return TQ_OK;
     uint32_t *keys_in = ctx->d_sort, *idx_in = keys_in + ctx->cm_quartets;
     uint32_t *keys_out = idx_in + ctx->cm_quartets, *idx_out = keys_out + ctx->cm_quartets;
     const uint64_t T = (uint64_t)ctx->T;
@@ -732,10 +733,22 @@ int tq_resolve_debug(tq_ctx *ctx, const uint32_t *quartets, int64_t Q, int subsa
     if (Q == 0) return TQ_OK;
     TQ_HIP(ctx, hipSetDevice(ctx->device));
     // taxon indices are checked on the host here; the kernel re-checks and flags them
-    for (int64_t i = 0; i < Q * 4; ++i)
-        if (quartets[i] >= (uint64_t)ctx->T)
-            return fail(ctx, TQ_ERR_INVALID_ARG, "quartet %lld has taxon index %u >= T=%lld", (long long)(i / 4),
-                        quartets[i], (long long)ctx->T);
+    // ... and the same pass notices input that already is in (a,b,c) order -- the lexicographic
+    // chunks of the reference's default mode (combinations.py:40-55) are -- so that the device sort
+    // (about twenty small kernels, most of the time of a chunk of a few thousand quartets) is skipped
+    bool sorted = true;
+    uint64_t prev_key = 0;
+    for (int64_t i = 0; i < Q; ++i) {
+        const uint32_t *q = quartets + i * 4;
+        for (int k = 0; k < 4; ++k)
+            if (q[k] >= (uint64_t)ctx->T)
+                return fail(ctx, TQ_ERR_INVALID_ARG, "quartet %lld has taxon index %u >= T=%lld", (long long)i, q[k],
+                            (long long)ctx->T);
+        const uint64_t key = ((uint64_t)q[0] << 42) | ((uint64_t)q[1] << 21) | (uint64_t)q[2];
+        sorted &= key >= prev_key;
+        prev_key = key;
+    }
+    ctx->input_sorted = sorted && ctx->T < (1 << 21);
     const bool debug = cmats || svds || ranks;
     const size_t o_q = 0;
     const size_t o_rstat = align_up(o_q + (size_t)Q * 16, 256);
@@ -769,6 +782,7 @@ int tq_resolve_debug(tq_ctx *ctx, const uint32_t *quartets, int64_t Q, int subsa
     out.svds = svds ? (double *)(base + o_sv) : nullptr;
     out.ranks = ranks ? (int32_t *)(base + o_rk) : nullptr;
     rc = launch(ctx, (const uint32_t *)(base + o_q), Q, subsample, debug, out, nullptr);
+    ctx->input_sorted = false;
     if (rc) return rc;
     if (staged) {
         TQ_HIP(ctx, hipMemcpyAsync((char *)ctx->h_stage + o_rstat, base + o_rstat, o_cm - o_rstat, hipMemcpyDeviceToHost,

@@ -26,3 +26,14 @@ for n in (1_000, 8_000, 31_250, 125_000):
         eng.resolve(q[i * n % (Q - n):][:n], True)
     dt = (time.perf_counter() - t0) / reps
     print(f"tq_resolve, chunk {n:7d}: {dt*1e3:7.3f} ms per call  {n/dt/1e6:6.2f} Mq/s")
+
+# the same chunks in lexicographic order (what the reference's full mode hands out): the device sort is skipped
+ql = q[np.lexsort((q[:, 3], q[:, 2], q[:, 1], q[:, 0]))]
+for n in (1_000, 8_000, 31_250, 125_000):
+    eng.resolve(ql[:n], True)
+    reps = max(3, 200_000 // n)
+    t0 = time.perf_counter()
+    for i in range(reps):
+        eng.resolve(ql[i * n % (Q - n):][:n], True)
+    dt = (time.perf_counter() - t0) / reps
+    print(f"tq_resolve, sorted chunk {n:7d}: {dt*1e3:7.3f} ms per call  {n/dt/1e6:6.2f} Mq/s")

@@ -155,13 +155,15 @@ def main():
     # two sets of output buffers: for N > 1 the all-gather of pass i runs (on RCCL's stream) while
     # the kernels of pass i+1 write the other set
     nbuf = 2 if world > 1 else 1
-    d_rstats = [torch.zeros((Q, 2), dtype=torch.int32, device=dev) for _ in range(nbuf)]
-    d_rscors = [torch.zeros((Q, 3), dtype=torch.float64, device=dev) for _ in range(nbuf)]
+    # one contiguous 32-byte-per-quartet slab per buffer set: [rstat u32[Q,2] | rscor f64[Q,3]], so that the
+    # result gather is ONE collective per step with no packing kernel (fixed-size records)
+    d_outs = [torch.zeros(32 * Q, dtype=torch.uint8, device=dev) for _ in range(nbuf)]
+    d_rstats = [o[:8 * Q].view(torch.int32).view(Q, 2) for o in d_outs]
+    d_rscors = [o[8 * Q:].view(torch.float64).view(Q, 3) for o in d_outs]
     d_flags = torch.zeros(Q, dtype=torch.uint8, device=dev)
     gdev = dev if args.backend == "nccl" else torch.device("cpu")
     if world > 1:
-        g_rstats = [torch.zeros((world * Q, 2), dtype=torch.int32, device=gdev) for _ in range(nbuf)]
-        g_rscors = [torch.zeros((world * Q, 3), dtype=torch.float64, device=gdev) for _ in range(nbuf)]
+        g_outs = [torch.zeros(world * 32 * Q, dtype=torch.uint8, device=gdev) for _ in range(nbuf)]
     stream = torch.cuda.current_stream().cuda_stream
     pending = [[], []]
     counter = [0]
@@ -176,10 +178,7 @@ def main():
                         d_flags.data_ptr(), stream)
         if world > 1:
             # result gather: every rank ends up with the whole node's rows in global order
-            pending[b] = [
-                dist.all_gather_into_tensor(g_rstats[b], d_rstats[b].to(gdev), async_op=True),
-                dist.all_gather_into_tensor(g_rscors[b], d_rscors[b].to(gdev), async_op=True),
-            ]
+            pending[b] = [dist.all_gather_into_tensor(g_outs[b], d_outs[b].to(gdev), async_op=True)]
 
     def fence():
         for ws in pending:

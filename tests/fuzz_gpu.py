@@ -1,0 +1,61 @@
+"""Randomised GPU-vs-oracle comparison over shapes, sparsity, locus structure, batch sizes and options.
+Usage: python tests/fuzz_gpu.py [seconds] [seed]   (prints one line per case, exits 1 on the first mismatch)"""
+import sys, time
+sys.path.insert(0, '/root/repo')
+import numpy as np
+from tetrad_amd import synth
+from tetrad_amd.engine import QuartetEngine
+from oracle import oracle
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+rng = np.random.default_rng(seed)
+eng = QuartetEngine(0)
+t_end = time.time() + budget
+case = 0
+while time.time() < t_end:
+    case += 1
+    T = int(rng.integers(4, 48))
+    S = int(rng.choice([1, 2, 31, 32, 33, 63, 64, 65, 2047, 2048, 2049, 4097, int(rng.integers(1, 7000))]))
+    p = float(rng.choice([0.005, 0.02, 0.05, 0.2]))
+    missing = float(rng.choice([0.0, 0.05, 0.3, 0.7, 0.95]))
+    tmparr, tmpmap = synth.simulate_tmparr(T, S, int(rng.integers(1 << 30)), p=p, missing=missing)
+    style = int(rng.integers(4))
+    if style == 1:                       # one locus per site
+        tmpmap[:, 0] = np.arange(S)
+    elif style == 2:                     # a single locus
+        tmpmap[:, 0] = 0
+    elif style == 3:                     # long runs with arbitrary (non-consecutive, non-monotone) ids
+        runs = np.cumsum(rng.integers(1, 200, size=S))
+        ids = rng.permutation(S + 5)[:S].astype(np.uint32)
+        tmpmap[:, 0] = ids[np.searchsorted(runs, np.arange(S), side="right")]
+    if rng.random() < 0.3:
+        tmparr[rng.integers(T)] = 78     # an all-missing taxon
+    Q = int(rng.choice([1, 3, 63, 64, 65, 255, 1000, 1024, 1025, int(rng.integers(1, 6000))]))
+    q = np.sort(np.stack([rng.permutation(T)[:4] for _ in range(Q)]), axis=1).astype(np.uint32)
+    if rng.random() < 0.5:
+        q = q[np.lexsort((q[:, 3], q[:, 2], q[:, 1], q[:, 0]))]
+    opts = {"scan_wg": int(rng.choice([0, 0, 1, 2, 8])), "batch": int(rng.choice([0, 0, 700])),
+            "svd_method": int(rng.choice([1, 1, 0])), "xcd_remap": int(rng.integers(2))}
+    for k, v in opts.items():
+        eng.set_option(k, v)
+    eng.set_data(tmparr, tmpmap)
+    for sub in (True, False):
+        rstat, rscor, flags = eng.resolve(q, sub)
+        _, o_rstat, o_rscor, o = oracle.new_infer_resolved_quartets(tmparr, tmpmap, q, sub, debug=True)
+        smax = np.maximum(o["svds"].max(axis=(1, 2)), 1e-300)[:, None]
+        ok_n = np.array_equal(rstat[:, 1], o_rstat[:, 1])
+        zero = o_rstat[:, 1] == 0
+        err = np.abs(rscor - o_rscor) / (np.abs(o_rscor) + 1e-6 * smax)
+        ok_s = bool((err[~zero] < 1e-6).all()) if (~zero).any() else True
+        plain = ((flags | o["flags"]) & 3) == 0
+        ok_t = np.array_equal(rstat[plain, 0], o_rstat[plain, 0])
+        ok_f = np.array_equal(flags & 1, o["flags"] & 1)
+        status = "ok" if (ok_n and ok_s and ok_t and ok_f) else "MISMATCH"
+        print(f"case {case} T={T} S={S} p={p} miss={missing} loc={style} Q={Q} sub={sub} {opts} "
+              f"flagged={int((~plain).sum())} maxerr={err[~zero].max() if (~zero).any() else 0:.1e} {status}", flush=True)
+        if status != "ok":
+            np.savez("/tmp/fuzz_fail.npz", tmparr=tmparr, tmpmap=tmpmap, q=q, sub=sub)
+            print(ok_n, ok_s, ok_t, ok_f)
+            sys.exit(1)
+print(f"{case} cases clean")

@@ -720,7 +720,10 @@ int tq_resolve_range_dev(tq_ctx *ctx, uint64_t first_rank, int64_t Q, int subsam
                        (const uint64_t *)nullptr, first_rank, Q, (int32_t)ctx->T, dq);
     TQ_HIP(ctx, hipGetLastError());
     OutPtrs out{d_rstat, d_rscor, d_flags, nullptr, nullptr, nullptr};
-    return launch(ctx, dq, Q, subsample, false, out, (hipStream_t)stream);
+    ctx->input_sorted = true;            // consecutive lexicographic ranks are in (a,b,c) order already
+    const int rc = launch(ctx, dq, Q, subsample, false, out, (hipStream_t)stream);
+    ctx->input_sorted = false;
+    return rc;
 }
 
 int tq_resolve_debug(tq_ctx *ctx, const uint32_t *quartets, int64_t Q, int subsample, uint32_t *rstat,

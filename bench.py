@@ -266,7 +266,7 @@ def main():
         }
         if args.phases in (1, 2):
             line["INVALID_diagnostic_phases"] = args.phases
-        if not args.no_cpu and args.phases in (0, 3):
+        if not args.no_cpu and args.phases in (0, 3) and world == 1:     # CPU leg: rank 0 at N=1 only
             cb, parity = cpu_baseline(tmparr, tmpmap, quartets, sub, rstat, rscor)
             line["cpu_baseline"] = cb
             line["parity_on_cpu_sample"] = parity

@@ -246,20 +246,22 @@ tq_scan_kernel(DevData d, const uint32_t *__restrict__ quartets, const uint32_t 
 
 
 // ------------------------------------------------------------------------------------
-// kernel 1, workgroup-cooperative form: NW wavefronts = NW neighbours of the (a,b)-sorted order.
-// Quartets that share their first two taxa share two of their four rows, so the workgroup fetches
-// the rows and plane records of taxa a and b ONCE per 2048-site step (waves 0-1 combine the code
-// bytes of a and b into the pattern partial (a<<6|b<<4) -- 2 KiB per step -- waves 2-3 copy the two
-// plane records), double-buffered in LDS with one barrier per step.  Every wave still streams its
-// own rows c and d straight to registers, from the NIBBLE-packed copy (1 KiB per row per step) plus
-// one 16-byte plane record each.  The kernel is bound by the L2 -> CU delivery rate (~17-18 TB/s
-// chip-wide for L2-resident data); bytes through that path per quartet-step fall from 12 KiB
-// (independent waves, byte rows) to 4 + 6/NW KiB.  A wave whose (a,b) differs from the leader's
-// (group boundary in the sorted order) builds its own partial from global memory instead; it
-// still takes part in the loads and barriers.
+// kernel 1, workgroup-cooperative form: NW wavefronts = NW neighbours of the (a,b,c)-sorted order,
+// one block of NW quartets per workgroup (grid = number of blocks, dispatched in sorted order).
+// Quartets that share their first two taxa share two of their four rows, so what depends only on
+// (a,b) is fetched and pre-combined ONCE per workgroup per 2048-site step by three 64-lane jobs dealt
+// round-robin to the waves: jobs 0-1 turn the nibble codes of a (x4 copy) and b into the pattern
+// partial ((a<<2)+b)<<4 of 16 sites per lane, job 2 turns the 12-byte plane records of a and b and
+// the run-begin word into {p0a, p1a, Ma|Mb, (p0a^p0b)|(p1a^p1b)} + B.  The image (3.25 KiB) is
+// double-buffered in LDS with one barrier per step.  Every wave streams its own rows c (x4 nibble
+// copy) and d (nibble copy) and their 12-byte plane records straight to registers, one step ahead:
+// 3.5 KiB per wave-step + 3.75/NW KiB shared (12 KiB for independent waves on byte rows).  A wave
+// whose (a,b) differs from the leader's (group boundary in the sorted order) builds its own partial
+// from the byte rows instead; it still takes part in the loads and barriers.  On c3 the kernel keeps
+// VALU 73 %, LDS 66 % and the L2 -> CU path ~80 % busy at the same time.
 // ------------------------------------------------------------------------------------
 struct OwnRegs {
-    uint4 c, d, pc, pd;      // nibble-packed codes of rows c and d (32 sites each), their plane records
+    uint4 c, d, pc, pd;      // nibble codes of rows c (x4) and d (32 sites each), their plane records (.w = 0)
 };
 
 // 16-byte load at a wave-uniform base + 32-bit per-lane byte offset (lets the compiler use the

@@ -4,15 +4,17 @@
 // (reference: tetrad/src/resolve_quartets.py:191-265 and the count kernels
 // :42-104).  Not a translation: the reference is an interpreted per-quartet
 // loop around a serial site scan and six LAPACK calls; here one 64-lane
-// wavefront owns a quartet during the site scan and one 16-lane group owns a
-// quartet during the singular-value stage.
+// wavefront owns a quartet during the site scan (four neighbours of the sorted
+// order form a workgroup that shares what depends on their common taxa a,b),
+// four lanes own a matrix during bidiagonalisation and one lane owns it during
+// the QR iteration.
 //
-// Data layout in HBM (built once per replicate by tq_set_data):
-//   rows   u8   [T][Sp]  base code 0..3 per site, missing/pad -> 0    (Sp = S rounded up to 2048;
-//                        inside each 2048-site step the bytes are stored in two 1 KiB panels, row_offset())
-//   planes u32x4[T][W]   per 32 sites: {missing bits, base bit 0, base bit 1, run-begin bits}
-//                        (W = Sp/32; run-begin = site starts a new locus run, same for every row,
-//                        replicated so that one 16-byte load brings everything a lane needs)
+// Data layout in HBM (built once per replicate by tq_set_data / tq_bootstrap):
+//   rows    u8   [T][Sp]   base code 0..3 per site, missing/pad -> 0  (Sp = S rounded up to 2048;
+//                          inside each 2048-site step the bytes sit in two 1 KiB panels, row_offset())
+//   nib     u8   [T][Sp/2] the same codes, two per byte (nib_offset()); nib4: codes pre-multiplied by 4
+//   planes  u32x4[T][W]    per 32 sites: {missing bits, base bit 0, base bit 1, run-begin bits}, W = Sp/32
+//   planes3 u32x3[T][W]    compact copy {missing, bit 0, bit 1}; runbeg u32 [W] run-begin bits, stored once
 //
 // Kernels (each in its own header of this directory, all included below into one translation unit):
 //   prepare.hpp   layout build, lexicographic unranking, sort keys

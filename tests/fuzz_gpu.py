@@ -15,7 +15,7 @@ t_end = time.time() + budget
 case = 0
 while time.time() < t_end:
     case += 1
-    T = int(rng.integers(4, 48))
+    T = int(rng.integers(4, 48)) if rng.random() < 0.9 else int(rng.integers(48, 400))
     S = int(rng.choice([1, 2, 31, 32, 33, 63, 64, 65, 2047, 2048, 2049, 4097, int(rng.integers(1, 7000))]))
     p = float(rng.choice([0.005, 0.02, 0.05, 0.2]))
     missing = float(rng.choice([0.0, 0.05, 0.3, 0.7, 0.95]))
@@ -40,6 +40,30 @@ while time.time() < t_end:
     for k, v in opts.items():
         eng.set_option(k, v)
     eng.set_data(tmparr, tmpmap)
+    if rng.random() < 0.25 and T >= 4:
+        # lexicographic rank range resolved on the device == the same quartets through the host API
+        import torch
+        from math import comb
+        total = comb(T, 4)
+        n = int(min(total, rng.integers(1, 3000)))
+        first = int(rng.integers(0, total - n + 1))
+        dev = torch.device("cuda:0")
+        dq = torch.zeros((n, 4), dtype=torch.int32, device=dev)
+        drs = torch.zeros((n, 2), dtype=torch.int32, device=dev)
+        dsc = torch.zeros((n, 3), dtype=torch.float64, device=dev)
+        dfl = torch.zeros(n, dtype=torch.uint8, device=dev)
+        sub0 = bool(rng.integers(2))
+        eng.resolve_range_dev(first, n, sub0, dq.data_ptr(), drs.data_ptr(), dsc.data_ptr(), dfl.data_ptr(),
+                              torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        qq = dq.cpu().numpy().astype(np.uint32)
+        want_q = synth.unrank_quartets(np.arange(first, first + n, dtype=np.uint64), T)
+        r2 = eng.resolve(qq, sub0)
+        same = (np.array_equal(qq, want_q) and np.array_equal(drs.cpu().numpy().astype(np.uint32), r2[0])
+                and np.array_equal(dsc.cpu().numpy(), r2[1]) and np.array_equal(dfl.cpu().numpy(), r2[2]))
+        print(f"case {case} range first={first} n={n} sub={sub0} {'ok' if same else 'MISMATCH'}", flush=True)
+        if not same:
+            sys.exit(1)
     for sub in (True, False):
         rstat, rscor, flags = eng.resolve(q, sub)
         _, o_rstat, o_rscor, o = oracle.new_infer_resolved_quartets(tmparr, tmpmap, q, sub, debug=True)

@@ -46,6 +46,18 @@ def test_numpy_spelled_out_variant_matches(oracle):
             np.testing.assert_array_equal(x, y)
 
 
+@pytest.mark.parametrize("mode", ["full", "sub"])
+def test_tuned_cpu_variant_matches_reference_vectors(oracle, mode):
+    """The batched values-only-SVD variant timed by bench.py as `cpu_baseline.tuned_variant`: same
+    integers as the reference's c1 run, scores to rounding (it makes one LAPACK call where the
+    reference makes two different ones)."""
+    g = load_golden("c1_T16_S5000")
+    q, rstat, rscor = oracle.new_infer_resolved_quartets_batched(
+        g["tmparr"], g["tmpmap"], g["quartets"], mode == "sub", chunk=500)
+    np.testing.assert_array_equal(rstat, g[f"{mode}_rstat"])
+    np.testing.assert_allclose(rscor, g[f"{mode}_rscor"], rtol=1e-10, atol=0)
+
+
 @pytest.mark.parametrize("case", ["tiny_T5_S37", "edge_T7_S130", "carry_T6_S2500"])
 def test_c_count_kernels_match_python_loops(oracle, case):
     g = load_golden(case)

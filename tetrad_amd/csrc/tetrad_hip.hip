@@ -90,6 +90,7 @@ struct tq_ctx {
     // count-matrix slab between the two kernels: u32 [batch][256]
     uint32_t *d_cm = nullptr;
     int64_t cm_quartets = 0;
+    int cm_slabs = 0;
     // (a,b)-sorted processing order of the current batch: keys/idx in, keys/idx out, cub temp
     uint32_t *d_sort = nullptr;     // 4 arrays of cm_quartets u32
     void *d_sort_tmp = nullptr;
@@ -116,7 +117,7 @@ struct tq_ctx {
     int waves_per_cu = 0;           // 0 = from the occupancy query
     int phases = 3;                 // diagnostics only: 1 = scan kernel only, 2 = SVD kernel only
     int scan_method = -1;           // 0 = EXEC-masked slot per site, 1 = set-bit walk, -1 = 1 if subsample else 0
-    int64_t batch = 1 << 20;        // quartets per scan->svd batch (1 GiB slab)
+    int64_t batch = 1 << 23;        // quartets per scan->svd batch (<= 8 GiB count slab + 9 GiB bidiagonals / values)
     // timing: per resolve call one (start, mid, stop) triple per batch
     bool timing = false;
     struct Ev { hipEvent_t e0, e1, e2; };
@@ -200,9 +201,11 @@ int ensure_stage(tq_ctx *ctx, size_t bytes)
     return TQ_OK;
 }
 
-int ensure_cm(tq_ctx *ctx, int64_t quartets)
+int ensure_cm(tq_ctx *ctx, int64_t quartets, int slabs = 1)
 {
-    if (quartets <= ctx->cm_quartets) return TQ_OK;
+    if (quartets <= ctx->cm_quartets && slabs <= ctx->cm_slabs) return TQ_OK;
+    if (quartets < ctx->cm_quartets) quartets = ctx->cm_quartets;
+    if (slabs < ctx->cm_slabs) slabs = ctx->cm_slabs;
     if (ctx->d_cm) (void)hipFree(ctx->d_cm);
     if (ctx->d_sort) (void)hipFree(ctx->d_sort);
     if (ctx->d_sort_tmp) (void)hipFree(ctx->d_sort_tmp);
@@ -215,7 +218,8 @@ int ensure_cm(tq_ctx *ctx, int64_t quartets)
     ctx->d_de = ctx->d_sv = nullptr;
     ctx->d_nsnps = nullptr;
     ctx->cm_quartets = 0;
-    TQ_HIP(ctx, hipMalloc((void **)&ctx->d_cm, (size_t)quartets * 1024 * 2));   // two slabs (overlap mode)
+    ctx->cm_slabs = 0;
+    TQ_HIP(ctx, hipMalloc((void **)&ctx->d_cm, (size_t)quartets * 1024 * (size_t)slabs));   // second slab: overlap mode only
     TQ_HIP(ctx, hipMalloc((void **)&ctx->d_de, (size_t)quartets * 3 * 32 * sizeof(double)));
     TQ_HIP(ctx, hipMalloc((void **)&ctx->d_sv, (size_t)quartets * 3 * 16 * sizeof(double)));
     TQ_HIP(ctx, hipMalloc((void **)&ctx->d_nsnps, (size_t)quartets * sizeof(uint32_t)));
@@ -226,6 +230,7 @@ int ensure_cm(tq_ctx *ctx, int64_t quartets)
     TQ_HIP(ctx, hipMalloc(&ctx->d_sort_tmp, tmp ? tmp : 16));
     ctx->sort_tmp_bytes = tmp;
     ctx->cm_quartets = quartets;
+    ctx->cm_slabs = slabs;
     return TQ_OK;
 }
 
@@ -476,7 +481,7 @@ int launch_overlapped(tq_ctx *ctx, const uint32_t *dq, int64_t Q, int subsample,
                       hipStream_t stream)
 {
     const int64_t sub = ctx->overlap;
-    int rc = ensure_cm(ctx, sub);
+    int rc = ensure_cm(ctx, sub, 2);
     if (rc) return rc;
     if (!ctx->sA) {
         TQ_HIP(ctx, hipStreamCreateWithFlags(&ctx->sA, hipStreamNonBlocking));
@@ -909,7 +914,7 @@ int tq_set_option(tq_ctx *ctx, const char *name, int64_t value)
     }
     if (!strcmp(name, "batch")) {
         if (value < 0) return fail(ctx, TQ_ERR_INVALID_ARG, "batch must be >= 0");
-        ctx->batch = value ? value : (1 << 20);
+        ctx->batch = value ? value : (1 << 23);
         return TQ_OK;
     }
     if (!strcmp(name, "phases")) {

@@ -29,7 +29,8 @@ def main():
     ap.add_argument("--svds", default="1", help="svd_method list: 0 Jacobi, 1 HQR")
     ap.add_argument("--wgs", default="4", help="scan_wg list: 1 one wave per quartet; 2/4/8/16 waves per cooperative workgroup")
     ap.add_argument("--svdwpcs", default="0", help="svd_wpc list: blocks per CU of the bidiag/bdsqr grids (0 default)")
-    ap.add_argument("--xcd", type=int, default=0, help="xcd_remap option")
+    ap.add_argument("--xcd", type=int, default=1, help="xcd_remap option")
+    ap.add_argument("--batch", type=int, default=0, help="quartets per scan/SVD batch (0 = library default 2^20)")
     ap.add_argument("--sort", default="none", choices=["none", "ab", "lex", "same"], help="order of the quartet list")
     args = ap.parse_args()
     import torch
@@ -50,6 +51,7 @@ def main():
     eng = QuartetEngine(0)
     eng.set_data(tmparr, tmpmap)
     eng.set_option("xcd_remap", args.xcd)
+    eng.set_option("batch", args.batch)
     d_q = torch.from_numpy(quartets.astype(np.int32)).to(dev)
     d_rstat = torch.zeros((Q, 2), dtype=torch.int32, device=dev)
     d_rscor = torch.zeros((Q, 3), dtype=torch.float64, device=dev)

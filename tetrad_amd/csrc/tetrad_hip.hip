@@ -881,7 +881,7 @@ int tq_set_option(tq_ctx *ctx, const char *name, int64_t value)
         return TQ_OK;
     }
     if (!strcmp(name, "ov_scan_wgs")) {
-        if (value < 1 || value > 4) return fail(ctx, TQ_ERR_INVALID_ARG, "ov_scan_wgs must be 1..4");
+        if (value < 0 || value > 8) return fail(ctx, TQ_ERR_INVALID_ARG, "ov_scan_wgs must be 0..8 (0: one block per workgroup)");
         ctx->ov_scan_wgs = (int)value;
         return TQ_OK;
     }

@@ -21,7 +21,7 @@ d_rstat = torch.zeros((Q, 2), dtype=torch.int32, device=dev)
 d_rscor = torch.zeros((Q, 3), dtype=torch.float64, device=dev)
 stream = torch.cuda.current_stream().cuda_stream
 ref = None
-variants = [(0, 1, 6)] + [(sub, wg, sw) for sub in (65536, 131072, 262144) for wg in (1, 2) for sw in (4, 6, 8, 10)]
+variants = [(0, 1, 6)] + [(sub, wg, 6) for sub in (65536, 131072, 262144, 524288) for wg in (0, 2, 3, 4)]
 res = {v: [] for v in variants}
 for rnd in range(3):
     for v in variants:

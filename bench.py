@@ -266,7 +266,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8 scan / u32 counts / f64 SVD", "data": "synthetic",
-            "config": {"workload": f"{args.config}: {T} taxa x {S} SNPs, {Q} random quartets per GPU, "
+            "config": {"workload": f"{args.config}: {T} taxa x {S} SNPs, {Q} {'random' if (qdef or args.quartets) else 'lexicographic (all)'} quartets per GPU, "
                                    f"subsample_snps={sub}", "quartets_per_gpu": Q, "taxa": T, "snps": S,
                        "subsample_snps": sub, "parallelism": f"quartet-sharded x{world} + all-gather"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -147,7 +147,8 @@ int tq_timing_read(tq_ctx *ctx, double *kernel_ms, int64_t *launches);
 int tq_timing_read_split(tq_ctx *ctx, double *total_ms, double *scan_ms, double *svd_ms, int64_t *calls);
 
 /* Tuning / diagnostic knobs (value 0 = library default unless noted).  Returns TQ_OK or an error.
- * Names: nrep, waves_per_cu, batch, order, scan_wg (waves per scan workgroup: 1, 2, 4, 8, 16), scan_method (-1 auto), svd_method (0 Jacobi,
+ * Names: nrep, waves_per_cu, batch (quartets per internal batch, default 2^23; device scratch is about
+ * 3.2 KB per quartet of the largest batch resolved so far), order, scan_wg (waves per scan workgroup: 1, 2, 4, 8, 16), scan_method (-1 auto), svd_method (0 Jacobi,
  * 1 Householder+QR), xcd_remap (1: scan workgroups of one XCD take a contiguous part of the sorted order),
  * svd_wpc (blocks per CU of the singular-value grids, 0 = one pass per block), overlap, ov_scan_wgs,
  * ov_svd_waves, phases (timing diagnostics).                                                     */

@@ -511,7 +511,7 @@ tq_scan_wg_kernel(DevData d, const uint32_t *__restrict__ quartets, const uint32
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const int bin = lane + WAVE * k;
-                out[bin] = work ? hist[bin] : 0u;
+                __builtin_nontemporal_store(work ? hist[bin] : 0u, &out[bin]);   // read next by another kernel: keep it out of L2
                 hist[bin] = 0;
             }
         }

@@ -27,13 +27,20 @@ def get_spans(maparr: np.ndarray) -> np.ndarray:
     return np.stack([starts, ends], axis=1).astype(np.int64)
 
 
+def draw_replicate(nloci: int, rng):
+    """The three draws of run_inference.py:117-123 on the project Generator, without touching the
+    GPU: `(lidxs, seed_shuffle, seed_ambig)` for `engine.bootstrap`.  Lets a driver prepare replicate
+    k+1 on the host while the kernels of replicate k run (replicate-sequential RNG
+    order, overlapped host work)."""
+    lidxs = rng.choice(nloci, nloci, replace=True)                 # :117
+    seed_shuffle = int(rng.integers(2**31))                        # :120
+    seed_ambig = int(rng.integers(2**31))                          # :123
+    return lidxs, seed_shuffle, seed_ambig
+
+
 def resample_tmp_database(engine: QuartetEngine, rng) -> int:
     """run_inference.py:99-143 on the device.  `engine.set_source(seqarr, spans)` must have been
     called.  Returns the replicate's number of sites; the replicate is resident on the GPU
     (use `engine.get_data()` to inspect it or to write it to a database)."""
     rng = np.random.default_rng(rng)                               # :105 (pass-through for a Generator)
-    nloci = engine.nloci
-    lidxs = rng.choice(nloci, nloci, replace=True)                 # :117
-    seed_shuffle = int(rng.integers(2**31))                        # :120
-    seed_ambig = int(rng.integers(2**31))                          # :123
-    return engine.bootstrap(lidxs, seed_shuffle, seed_ambig)
+    return engine.bootstrap(*draw_replicate(engine.nloci, rng))

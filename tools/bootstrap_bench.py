@@ -45,3 +45,24 @@ for rep in range(reps):
     print(f"rep {rep}: S={Srep} bootstrap {tb[-1]:.2f} ms, host quartet sampling {ts[-1]:.1f} ms, "
           f"unrank+resolve {tr[-1]:.2f} ms, flagged rows {int((fl != 0).sum())}")
 print(f"median: bootstrap {np.median(tb):.2f} ms, resolve {np.median(tr):.2f} ms per replicate of {Q} quartets")
+
+# The same flow pipelined: the host draws of replicate k+1 (locus indices, the two seeds, the rank
+# sample -- in the reference's order on the one Generator) are made while the kernels of replicate k run.
+rng = np.random.default_rng(synth.CONFIG_SEEDS["c5"])
+def draws():
+    d = bootstrap.draw_replicate(eng.nloci, rng)
+    return d, rng.choice(synth.comb(T, 4), size=Q, replace=False).astype(np.int64)
+d_q = torch.zeros((Q, 4), dtype=torch.int32, device=dev)
+nxt = draws()
+torch.cuda.synchronize(); t0 = time.perf_counter()
+for rep in range(reps):
+    (lidxs, s1, s2), idx = nxt
+    eng.bootstrap(lidxs, s1, s2)
+    d_ranks = torch.from_numpy(idx).to(dev)
+    eng.unrank_dev(d_ranks.data_ptr(), Q, d_q.data_ptr(), stream)
+    eng.resolve_dev(d_q.data_ptr(), Q, True, d_rstat.data_ptr(), d_rscor.data_ptr(), d_flags.data_ptr(), stream)
+    if rep + 1 < reps:
+        nxt = draws()                   # host work under the GPU's
+    torch.cuda.synchronize()
+dt = (time.perf_counter() - t0) / reps
+print(f"pipelined: {dt*1e3:.1f} ms per replicate ({Q/dt/1e6:.1f} M quartets/s including bootstrap and sampling)")

@@ -95,15 +95,25 @@ constexpr int PAT_STRIDE = 36;   // bytes per lane in the pattern park: 9 dwords
                                  // the first counted sites of neighbouring lanes tend to have similar indices)
 
 // pat[j] holds the 8-bit patterns (a<<6|b<<4|c<<2|d) of sites 4j..4j+3 of this lane, one per byte
-template <int NREP, int METHOD>
-__device__ __forceinline__ void hist_patterns(const uint32_t (&pat)[8], uint32_t C, uint32_t *hrep, uint8_t *park)
+struct NoHook {
+    __device__ __forceinline__ void operator()() const {}
+};
+
+// `after_build` runs once the patterns are in their final place (registers for METHOD 0, the LDS park
+// for METHOD 1) and before the histogram increments: the cooperative kernel issues the next step's
+// row loads there, so that they fly under the increments and need no second register set.
+template <int NREP, int METHOD, typename Hook = NoHook>
+__device__ __forceinline__ void hist_patterns(const uint32_t (&pat)[8], uint32_t C, uint32_t *hrep, uint8_t *park,
+                                              Hook after_build = Hook())
 {
     if (METHOD == 2) {
         uint32_t acc = C;
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc ^= pat[j];
         asm volatile("" ::"v"(acc));
+        after_build();
     } else if (METHOD == 0) {
+        after_build();
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
 #pragma unroll
@@ -117,6 +127,7 @@ __device__ __forceinline__ void hist_patterns(const uint32_t (&pat)[8], uint32_t
         uint32_t *pw = reinterpret_cast<uint32_t *>(park);
 #pragma unroll
         for (int j = 0; j < 8; ++j) pw[j] = pat[j];
+        after_build();
         // set-bit walk, software pipelined: the pattern byte of the NEXT counted site is requested
         // before the histogram increment of the current one (two alternating registers: a copy
         // would wait for the read it copies)
@@ -423,14 +434,14 @@ tq_scan_wg_kernel(DevData d, const uint32_t *__restrict__ quartets, const uint32
             sx[i] = fetch_x(job_of(i), 0);
             sy[i] = fetch_y(job_of(i), 0);
         }
-        OwnRegs A, B;
+        OwnRegs A;
         load_own(A, nib, nib4, planes3, oo, 0);
 #pragma unroll
         for (int i = 0; i < JPW; ++i) publish(shared_ab[0], job_of(i), sx[i], sy[i]);
         uint32_t tile_carry = 0;
         __syncthreads();
 
-        auto step = [&](const OwnRegs &own, int t) {
+        auto step = [&](OwnRegs &own, int t, int tnext) {
             if (!work) return;
             uint4 ab0, ab1, r1;                            // abp panels (sites 0-15, 16-31), combined planes
             uint32_t Bw;                                   // run-begin bits
@@ -467,43 +478,28 @@ tq_scan_wg_kernel(DevData d, const uint32_t *__restrict__ quartets, const uint32
             pat[2] = and_or(s1, m, ab0.z); pat[3] = and_or(s1 >> 4, m, ab0.w);
             pat[4] = and_or(s2, m, ab1.x); pat[5] = and_or(s2 >> 4, m, ab1.y);
             pat[6] = and_or(s3, m, ab1.z); pat[7] = and_or(s3 >> 4, m, ab1.w);
-            hist_patterns<1, METHOD == 3 ? 1 : METHOD>(pat, C, hist, park);
+            hist_patterns<1, METHOD == 3 ? 1 : METHOD>(pat, C, hist, park, [&]() {
+                load_own(own, nib, nib4, planes3, oo, tnext);
+                __builtin_amdgcn_sched_barrier(0);
+            });
         };
 
-        for (int t = 0; t < d.ntiles; t += 2) {
-            // ---- even step: prefetch t+1 (own -> B, shared -> registers), process A ----
-            {
-                const int tn = min(t + 1, last);
+        for (int t = 0; t < d.ntiles; ++t) {
+            // the shared pieces of step t+1 go to registers now and to LDS after this step's work; the own
+            // rows of step t+1 are requested from inside step(), as soon as this step no longer needs the
+            // registers they land in (the index is clamped: the last step re-reads its own tile)
+            const int tn = min(t + 1, last);
 #pragma unroll
-                for (int i = 0; i < JPW; ++i) {
-                    sx[i] = fetch_x(job_of(i), tn);
-                    sy[i] = fetch_y(job_of(i), tn);
-                }
-                load_own(B, nib, nib4, planes3, oo, tn);
-                __builtin_amdgcn_sched_barrier(0);
-                step(A, t);
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int i = 0; i < JPW; ++i) publish(shared_ab[(t + 1) & 1], job_of(i), sx[i], sy[i]);
-                if (METHOD != 3) __syncthreads();      // METHOD 3 = timing diagnostic without the barrier
+            for (int i = 0; i < JPW; ++i) {
+                sx[i] = fetch_x(job_of(i), tn);
+                sy[i] = fetch_y(job_of(i), tn);
             }
-            if (t + 1 >= d.ntiles) break;
-            // ---- odd step ----
-            {
-                const int tn = min(t + 2, last);
+            __builtin_amdgcn_sched_barrier(0);
+            step(A, t, tn);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int i = 0; i < JPW; ++i) {
-                    sx[i] = fetch_x(job_of(i), tn);
-                    sy[i] = fetch_y(job_of(i), tn);
-                }
-                load_own(A, nib, nib4, planes3, oo, tn);
-                __builtin_amdgcn_sched_barrier(0);
-                step(B, t + 1);
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int i = 0; i < JPW; ++i) publish(shared_ab[t & 1], job_of(i), sx[i], sy[i]);
-                if (METHOD != 3) __syncthreads();
-            }
+            for (int i = 0; i < JPW; ++i) publish(shared_ab[(t + 1) & 1], job_of(i), sx[i], sy[i]);
+            if (METHOD != 3) __syncthreads();      // METHOD 3 = timing diagnostic without the barrier
         }
         // store the 256 counts of this wave's quartet and clear its histogram
         if (have) {

@@ -265,11 +265,12 @@ tq_scan_kernel(DevData d, const uint32_t *__restrict__ quartets, const uint32_t 
 // partial ((a<<2)+b)<<4 of 16 sites per lane, job 2 turns the 12-byte plane records of a and b and
 // the run-begin word into {p0a, p1a, Ma|Mb, (p0a^p0b)|(p1a^p1b)} + B.  The image (3.25 KiB) is
 // double-buffered in LDS with one barrier per step.  Every wave streams its own rows c (x4 nibble
-// copy) and d (nibble copy) and their 12-byte plane records straight to registers, one step ahead:
+// copy) and d (nibble copy) and their 12-byte plane records straight to registers (one register set:
+// the loads of step t+1 are issued inside step t once the pattern bytes are parked, 72 VGPRs = 7 waves/SIMD):
 // 3.5 KiB per wave-step + 3.75/NW KiB shared (12 KiB for independent waves on byte rows).  A wave
 // whose (a,b) differs from the leader's (group boundary in the sorted order) builds its own partial
 // from the byte rows instead; it still takes part in the loads and barriers.  On c3 the kernel keeps
-// VALU 73 %, LDS 66 % and the L2 -> CU path ~80 % busy at the same time.
+// VALU 77 %, LDS 78 % and the L2 -> CU path ~90 % busy at the same time.
 // ------------------------------------------------------------------------------------
 struct OwnRegs {
     uint4 c, d, pc, pd;      // nibble codes of rows c (x4) and d (32 sites each), their plane records (.w = 0)

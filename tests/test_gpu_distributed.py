@@ -1,0 +1,74 @@
+"""The N>1 product path with the real engine: two ranks (gloo collective, both on the one GPU of the
+test box) resolve a batch through `distributor.resolve_sharded` / `distributor.distributor`; every rank
+must end up with the rows of a single-engine run, bitwise, and rank 0 must write the same TSV.
+(The "nccl" branch differs only in where the gathered tensor lives; it needs one GPU per rank.)"""
+import os
+import socket
+import subprocess
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from conftest import load_golden
+
+REPO = Path(__file__).resolve().parents[1]
+
+WORKER = r'''
+import os, sys
+import numpy as np
+sys.path.insert(0, sys.argv[1])
+import torch, torch.distributed as dist
+from tetrad_amd import distributor as D
+rank, world, port, out = int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], sys.argv[5]
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=port, RANK=str(rank), WORLD_SIZE=str(world))
+torch.cuda.set_device(0)
+dist.init_process_group("gloo", rank=rank, world_size=world)
+g = np.load(os.path.join(sys.argv[1], "tests", "golden", "c1_T16_S5000.npz"))
+qr = g["quartets"][:1501]                      # odd count: exercises the padded slab
+for sub in (True, False):
+    _, rstat, rscor, flags = D.resolve_sharded(g["tmparr"], g["tmpmap"], qr, sub)
+    np.savez(out + f".{int(sub)}.{rank}.npz", rstat=rstat, rscor=rscor, flags=flags)
+db = out + ".db.npz"
+if rank == 0:
+    np.savez(db, tmparr=g["tmparr"], tmpmap=g["tmpmap"])
+dist.barrier()
+chunks = [qr[i:i + 400].tolist() for i in range(0, 1501, 400)]
+D.distributor(db, out + ".tsv", 16, iter(chunks), True, None)
+dist.barrier()
+dist.destroy_process_group()
+'''
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return str(s.getsockname()[1])
+
+
+@pytest.mark.gpu
+def test_two_ranks_with_the_engine_equal_one_engine(tmp_path):
+    from tetrad_amd import distributor as D
+    from tetrad_amd.engine import QuartetEngine
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    port, out = _free_port(), str(tmp_path / "res")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = [subprocess.Popen([sys.executable, str(script), str(REPO), str(r), "2", port, out], env=env)
+             for r in range(2)]
+    for p in procs:
+        assert p.wait(timeout=600) == 0
+    g = load_golden("c1_T16_S5000")
+    q = g["quartets"][:1501]
+    eng = QuartetEngine(0)
+    eng.set_data(g["tmparr"], g["tmpmap"])
+    for sub in (True, False):
+        rstat, rscor, flags = eng.resolve(q, sub)
+        for r in range(2):
+            z = np.load(out + f".{int(sub)}.{r}.npz")
+            np.testing.assert_array_equal(z["rstat"], rstat)
+            np.testing.assert_array_equal(z["rscor"], rscor)
+            np.testing.assert_array_equal(z["flags"], flags)
+    rstat, rscor, _ = eng.resolve(q, True)
+    assert Path(out + ".tsv").read_text() == D.format_tsv(q, rscor, rstat)

@@ -102,10 +102,13 @@ def resolve_sharded(tmparr, tmpmap, quartets, subsample_snps: bool = True, *, gr
         backend = dist.get_backend(group)
     else:
         world, rank, backend = 1, 0, None
+    lo, hi = shard_bounds(Q, world)[rank]
+    if compute is None and world > 1:
+        return _resolve_sharded_device(tmparr, tmpmap, quartets, subsample_snps, group, world, rank, backend,
+                                       lo, hi, device)
     if compute is None:
         dev_id = torch.cuda.current_device() if device is None else torch.device(device).index
         compute = gpu_compute(dev_id)
-    lo, hi = shard_bounds(Q, world)[rank]
     rstat, rscor, flags = compute(tmparr, tmpmap, quartets[lo:hi], subsample_snps)
     if world == 1:
         return quartets, rstat, rscor, flags
@@ -120,6 +123,51 @@ def resolve_sharded(tmparr, tmpmap, quartets, subsample_snps: bool = True, *, gr
     g = gathered.cpu().numpy().reshape(world, slab, RECORD_WORDS)
     parts = [g[r, :b - a] for r, (a, b) in enumerate(shard_bounds(Q, world))]
     rstat, rscor, flags = unpack_records(np.concatenate(parts, axis=0))
+    return quartets, rstat, rscor, flags
+
+
+def _resolve_sharded_device(tmparr, tmpmap, quartets, subsample_snps, group, world, rank, backend, lo, hi, device):
+    """The N>1 path with the HIP engine: the rank's rows never visit the host before the gather.  The
+    engine writes `[rstat u32[slab,2] | rscor f64[slab,3] | flags u8[slab]]` into ONE device slab
+    (33 bytes per quartet, padded to ceil(Q/world) rows), one all-gather (RCCL over xGMI with the
+    "nccl" backend) collects the slabs of all ranks, one D2H brings them to the host."""
+    import torch
+    import torch.distributed as dist
+    from .resolve_quartets import _ensure_resident, get_engine
+
+    Q = quartets.shape[0]
+    dev_id = torch.cuda.current_device() if device is None else torch.device(device).index
+    dev = torch.device("cuda", dev_id)
+    eng = get_engine(dev_id)
+    _ensure_resident(eng, tmparr, tmpmap)
+    slab = -(-Q // world)
+    n = hi - lo
+    blk = (33 * slab + 7) // 8 * 8                   # bytes per rank, 8-byte aligned
+    local = torch.zeros(blk, dtype=torch.uint8, device=dev)
+    if n:
+        d_q = torch.from_numpy(quartets[lo:hi].astype(np.int32)).to(dev)
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        eng.resolve_dev(d_q.data_ptr(), n, subsample_snps, local.data_ptr(), local.data_ptr() + 8 * slab,
+                        local.data_ptr() + 32 * slab, stream)
+    if backend == "nccl":
+        gathered = torch.empty(world * blk, dtype=torch.uint8, device=dev)
+        dist.all_gather_into_tensor(gathered, local, group=group)
+        g = gathered.cpu().numpy()
+    else:                                           # gloo rehearsal: the collective runs on host tensors
+        torch.cuda.synchronize(dev)
+        loc = local.cpu()
+        gathered = torch.empty(world * blk, dtype=torch.uint8)
+        dist.all_gather_into_tensor(gathered, loc, group=group)
+        g = gathered.numpy()
+    g = g.reshape(world, blk)
+    rstat = np.empty((Q, 2), dtype=np.uint32)
+    rscor = np.empty((Q, 3), dtype=np.float64)
+    flags = np.empty(Q, dtype=np.uint8)
+    for r, (a, b) in enumerate(shard_bounds(Q, world)):
+        m = b - a
+        rstat[a:b] = g[r, :8 * slab].view(np.uint32).reshape(slab, 2)[:m]
+        rscor[a:b] = g[r, 8 * slab:32 * slab].view(np.float64).reshape(slab, 3)[:m]
+        flags[a:b] = g[r, 32 * slab:33 * slab][:m]
     return quartets, rstat, rscor, flags
 
 

@@ -16,9 +16,12 @@
  *   - one context per (process, device).  A context is not thread-safe;
  *     distinct contexts are independent.  The library keeps no host pointer
  *     after a call returns.
- *   - host-buffer entry points (tq_set_data, tq_resolve, tq_resolve_debug)
- *     are synchronous.  *_dev entry points take device pointers, enqueue on
- *     the given HIP stream and return without synchronising.
+ *   - host-buffer entry points (tq_set_data, tq_resolve, tq_resolve_to_host,
+ *     tq_resolve_debug) are synchronous: results are in the caller's arrays on
+ *     return.  Inside, kernels and copies run on the context's own streams and the
+ *     result D2H of one piece overlaps the kernels of the next.  *_dev entry points
+ *     take device pointers, enqueue on the given HIP stream and return without
+ *     synchronising.
  */
 #ifndef TETRAD_HIP_H
 #define TETRAD_HIP_H
@@ -49,7 +52,10 @@ enum {
                                   resolve_quartets.py:230-232)                      */
     TQ_FLAG_DEGENERATE = 2,    /* two lowest scores within 1e-9 * sigma_max: argmin is
                                   decided by SVD rounding noise in any implementation */
-    TQ_FLAG_BAD_INDEX = 4      /* a taxon index was >= T; row treated as zero-data   */
+    TQ_FLAG_BAD_INDEX = 4,     /* a taxon index was >= T; row treated as zero-data   */
+    TQ_FLAG_NO_CONVERGENCE = 8 /* a singular-value iteration hit its sweep cap; the row holds the
+                                  unconverged values (reference: np.linalg.svd raises LinAlgError,
+                                  resolve_quartets.py:242; the Python mirror raises it too)   */
 };
 
 /* Create / destroy a context bound to HIP device `device_id`.
@@ -108,8 +114,24 @@ int tq_data_shape(tq_ctx *ctx, int64_t *T, int64_t *S);
 int tq_resolve(tq_ctx *ctx, const uint32_t *quartets, int64_t Q, int subsample,
                uint32_t *rstat, double *rscor, uint8_t *flags);
 
-/* Same, device pointers, asynchronous on `stream` (a hipStream_t; NULL = the
- * default stream).  This is what bench.py times (inputs resident in HBM).        */
+/* Page-locked host memory from a process-wide pool (blocks are recycled: pinning pages costs about
+ * as much as a resolve call).  Result arrays (and quartet arrays) that live in such a block -- or in
+ * any other page-locked memory -- are read / written by the copy engine directly, asynchronously under
+ * the kernels; pageable arrays work too, through pinned staging pieces and one host memcpy per piece.
+ * Blocks are independent of any context and may outlive it.  No reference counterpart (the reference
+ * returns fresh NumPy arrays, resolve_quartets.py:253-265; the ctypes binding wraps such blocks as NumPy
+ * arrays).                                                                                       */
+int tq_host_alloc(int64_t bytes, void **out);
+int tq_host_free(void *p);
+
+/* Quartets already on the device, results to host arrays (synchronous): what bench.py times as one
+ * step -- inputs resident in HBM, result D2H inside the step.
+ * Replaces: the same function as tq_resolve.                                                     */
+int tq_resolve_to_host(tq_ctx *ctx, const uint32_t *d_quartets, int64_t Q, int subsample,
+                       uint32_t *rstat, double *rscor, uint8_t *flags);
+
+/* Same, device pointers in and out, asynchronous on `stream` (a hipStream_t; NULL = the
+ * default stream).                                                                        */
 int tq_resolve_dev(tq_ctx *ctx, const uint32_t *d_quartets, int64_t Q, int subsample,
                    uint32_t *d_rstat, double *d_rscor, uint8_t *d_flags, void *stream);
 
@@ -120,6 +142,17 @@ int tq_resolve_dev(tq_ctx *ctx, const uint32_t *d_quartets, int64_t Q, int subsa
 int tq_resolve_range_dev(tq_ctx *ctx, uint64_t first_rank, int64_t Q, int subsample,
                          uint32_t *d_quartets, uint32_t *d_rstat, double *d_rscor,
                          uint8_t *d_flags, void *stream);
+
+/* The two stages of tq_resolve_dev as separate calls, for callers that ship results in pieces (the
+ * multi-GPU path gathers and copies piece i while piece i+1 is computed):
+ *   tq_scan_dev  orders and scans quartets [0,Q) into the context's count slab (Q <= option "batch");
+ *   tq_svd_dev   turns rows [q0, q0+n) of that scanned batch into results; d_rstat / d_rscor / d_flags
+ *                point at the outputs OF ROW q0 (so pieces can live in separate slabs).
+ * Both enqueue on `stream`.  Replaces: the two halves of new_infer_resolved_quartets
+ * (resolve_quartets.py:208-226 and :236-251).                                                    */
+int tq_scan_dev(tq_ctx *ctx, const uint32_t *d_quartets, int64_t Q, int subsample, void *stream);
+int tq_svd_dev(tq_ctx *ctx, int64_t q0, int64_t n, uint32_t *d_rstat, double *d_rscor,
+               uint8_t *d_flags, void *stream);
 
 /* Random-mode quartet generation on the device: unranks host-sampled
  * lexicographic ranks (combinations.py:94-114) into d_quartets.                    */
@@ -145,18 +178,24 @@ int tq_timing_read(tq_ctx *ctx, double *kernel_ms, int64_t *launches);
 /* Same, split by kernel: total = scan + svd milliseconds summed over the `calls` resolve calls
  * made since the last read (a resolve call launches one scan + one SVD kernel per batch).     */
 int tq_timing_read_split(tq_ctx *ctx, double *total_ms, double *scan_ms, double *svd_ms, int64_t *calls);
+/* Same, per kernel: ms[0] ordering (key + radix sort), ms[1] site scan, ms[2] bidiagonalisation (or the
+ * whole Jacobi kernel with svd_method 0), ms[3] bidiagonal QR, ms[4] scores; entries beyond n_ms are
+ * not written, entries beyond 4 are set to 0.                                                    */
+int tq_timing_read_kernels(tq_ctx *ctx, double *ms, int n_ms, int64_t *calls);
 
 /* Tuning / diagnostic knobs (value 0 = library default unless noted).  Returns TQ_OK or an error.
  * Names: nrep, waves_per_cu, batch (quartets per internal batch, default 2^23; device scratch is about
  * 3.2 KB per quartet of the largest batch resolved so far), order, scan_wg (waves per scan workgroup: 1, 2, 4, 8, 16), scan_method (-1 auto), svd_method (0 Jacobi,
  * 1 Householder+QR), xcd_remap (1: scan workgroups of one XCD take a contiguous part of the sorted order),
- * svd_wpc (blocks per CU of the singular-value grids, 0 = one pass per block), overlap, ov_scan_wgs,
- * ov_svd_waves, phases (timing diagnostics).                                                     */
+ * svd_wpc (blocks per CU of the singular-value grids, 0 = one pass per block), svd_chunk (quartets per
+ * pass of the singular-value stage = per result-copy piece, default 2^17), bdsqr_maxit (QR sweeps per
+ * singular value before TQ_FLAG_NO_CONVERGENCE, default 60), phases (timing diagnostics).         */
 int tq_set_option(tq_ctx *ctx, const char *name, int64_t value);
 
 /* Test hook: copy the scratch of the last resolve call to the host.  which = 0: count slab
- * u32[n][256]; 1: bidiagonals f64[3n][32] (d[16], e[16]); 2: singular values f64[3n][16] (unsorted),
- * n = quartets of the last batch.  No reference counterpart.                                   */
+ * u32[n][256] of the last scan batch; 1: bidiagonals f64[3m][32] (d[16], e[16]); 2: singular values
+ * f64[3m][16] (unsorted, sign bit = not converged), m = quartets of the last singular-value chunk.
+ * No reference counterpart.                                                                    */
 int tq_debug_fetch(tq_ctx *ctx, int which, void *dst, int64_t bytes);
 
 /* Text for the consumers right after the hot path (host code, no device involved).

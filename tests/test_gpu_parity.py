@@ -279,26 +279,130 @@ def test_scan_grid_shapes(engine, Q):
 
 
 def test_pipeline_options_do_not_change_results(engine):
-    """Two-stream overlapped pipeline, per-wave scan kernel, natural order, small batches: all must
-    give bitwise the same rows as the default configuration."""
+    """Per-wave scan kernel, natural order, small scan batches, small singular-value chunks (= result-copy
+    pieces of the host API): all must give bitwise the same rows as the default configuration."""
     g = load_golden("c1_T16_S5000")
     engine.set_data(g["tmparr"], g["tmpmap"])
     q = np.tile(g["quartets"], (3, 1))
     base = engine.resolve(q, True)
+    defaults = {"scan_wg": 0, "xcd_remap": 1, "order": 1, "scan_method": -1, "waves_per_cu": 0, "svd_wpc": 0,
+                "batch": 0, "svd_chunk": 0}
     try:
-        for opts in ({"overlap": 1024}, {"scan_wg": 1}, {"scan_wg": 2}, {"scan_wg": 8}, {"scan_wg": 16}, {"xcd_remap": 0}, {"waves_per_cu": 12}, {"svd_wpc": 8}, {"order": 0}, {"batch": 700}, {"scan_method": 0},
-                     {"overlap": 512, "ov_scan_wgs": 2, "ov_svd_waves": 4}):
+        for opts in ({"scan_wg": 1}, {"scan_wg": 2}, {"scan_wg": 8}, {"scan_wg": 16}, {"xcd_remap": 0},
+                     {"waves_per_cu": 12}, {"svd_wpc": 8}, {"order": 0}, {"batch": 700}, {"scan_method": 0},
+                     {"svd_chunk": 1000}, {"svd_chunk": 64, "batch": 999}, {"svd_chunk": 1}):
             for k, v in opts.items():
                 engine.set_option(k, v)
-            got = engine.resolve(q, True)
-            for a, b in zip(base, got):
+            if opts.get("svd_chunk") == 1:
+                got = engine.resolve(q[:40], True)
+                want = tuple(x[:40] for x in base)
+            else:
+                got, want = engine.resolve(q, True), base
+            for a, b in zip(want, got):
                 np.testing.assert_array_equal(a, b)
             for k in opts:
-                engine.set_option(k, {"scan_wg": 0, "xcd_remap": 1, "order": 1, "scan_method": -1, "ov_scan_wgs": 1,
-                                      "ov_svd_waves": 6}.get(k, 0))
+                engine.set_option(k, defaults[k])
     finally:
-        for k, v in (("overlap", 0), ("scan_wg", 0), ("xcd_remap", 1), ("waves_per_cu", 0), ("svd_wpc", 0), ("order", 1), ("batch", 0), ("scan_method", -1)):
+        for k, v in defaults.items():
             engine.set_option(k, v)
+
+
+def test_pageable_and_pinned_result_arrays_agree(engine):
+    """tq_resolve writes page-locked result arrays with the copy engine directly and pageable ones through
+    pinned staging pieces + host memcpy; tq_resolve_to_host takes the quartets from the device.  Several
+    pieces per call (svd_chunk), last piece ragged."""
+    import ctypes
+    import torch
+    from tetrad_amd.engine import pinned_empty
+    g = load_golden("c1_T16_S5000")
+    engine.set_data(g["tmparr"], g["tmpmap"])
+    q = np.tile(g["quartets"], (4, 1))[:7001]
+    Q = len(q)
+    want = engine.resolve(q, True)
+    lib, h = engine._lib, engine._h
+    try:
+        engine.set_option("svd_chunk", 1500)
+        for pinned in (False, True):
+            alloc = pinned_empty if pinned else (lambda shape, dt: np.full(shape, 7, dtype=dt))
+            rstat, rscor, flags = alloc((Q, 2), np.uint32), alloc((Q, 3), np.float64), alloc(Q, np.uint8)
+            rc = lib.tq_resolve(h, ctypes.c_void_p(q.ctypes.data), Q, 1, ctypes.c_void_p(rstat.ctypes.data),
+                                ctypes.c_void_p(rscor.ctypes.data), ctypes.c_void_p(flags.ctypes.data))
+            assert rc == 0
+            for a, b in zip(want, (rstat, rscor, flags)):
+                np.testing.assert_array_equal(a, b)
+            # flags may be NULL
+            rstat2, rscor2 = alloc((Q, 2), np.uint32), alloc((Q, 3), np.float64)
+            rc = lib.tq_resolve(h, ctypes.c_void_p(q.ctypes.data), Q, 1, ctypes.c_void_p(rstat2.ctypes.data),
+                                ctypes.c_void_p(rscor2.ctypes.data), None)
+            assert rc == 0
+            np.testing.assert_array_equal(rstat2, want[0])
+            np.testing.assert_array_equal(rscor2, want[1])
+        dq = torch.from_numpy(q.astype(np.int32)).to("cuda:0")
+        got = engine.resolve_to_host(dq.data_ptr(), Q, True)
+        for a, b in zip(want, got):
+            np.testing.assert_array_equal(a, b)
+        out = (np.zeros((Q, 2), np.uint32), np.zeros((Q, 3), np.float64), np.zeros(Q, np.uint8))
+        engine.resolve_to_host(dq.data_ptr(), Q, True, out=out)
+        for a, b in zip(want, out):
+            np.testing.assert_array_equal(a, b)
+    finally:
+        engine.set_option("svd_chunk", 0)
+
+
+def test_scan_then_svd_in_pieces(engine):
+    """tq_scan_dev + tq_svd_dev over arbitrary row ranges, pieces written to separate slabs, == tq_resolve."""
+    import torch
+    g = load_golden("c1_T16_S5000")
+    engine.set_data(g["tmparr"], g["tmpmap"])
+    q = np.tile(g["quartets"], (2, 1))[:3001]
+    Q = len(q)
+    want = engine.resolve(q, False)
+    dev = torch.device("cuda:0")
+    dq = torch.from_numpy(q.astype(np.int32)).to(dev)
+    stream = torch.cuda.current_stream().cuda_stream
+    engine.scan_dev(dq.data_ptr(), Q, False, stream)
+    pieces = [(0, 1000), (1000, 1), (1001, 1999), (3000, 1)]
+    outs = []
+    for q0, n in reversed(pieces):                       # any order
+        rs = torch.zeros((n, 2), dtype=torch.int32, device=dev)
+        sc = torch.zeros((n, 3), dtype=torch.float64, device=dev)
+        fl = torch.zeros(n, dtype=torch.uint8, device=dev)
+        engine.svd_dev(q0, n, rs.data_ptr(), sc.data_ptr(), fl.data_ptr(), stream)
+        outs.append((q0, rs, sc, fl))
+    torch.cuda.synchronize()
+    for q0, rs, sc, fl in outs:
+        n = rs.shape[0]
+        np.testing.assert_array_equal(rs.cpu().numpy().astype(np.uint32), want[0][q0:q0 + n])
+        np.testing.assert_array_equal(sc.cpu().numpy(), want[1][q0:q0 + n])
+        np.testing.assert_array_equal(fl.cpu().numpy(), want[2][q0:q0 + n])
+    from tetrad_amd.engine import TetradHipError
+    with pytest.raises(TetradHipError):
+        engine.svd_dev(3000, 2, outs[0][1].data_ptr(), outs[0][2].data_ptr(), 0, stream)   # beyond the scanned batch
+
+
+def test_sweep_cap_is_flagged(engine):
+    """A singular-value iteration that hits its sweep cap must say so (numpy raises LinAlgError there):
+    with the cap forced to one sweep per value most matrices do not converge -> TQ_FLAG_NO_CONVERGENCE and
+    the Python mirror raises; with the default cap no row of any golden case carries the flag."""
+    from tetrad_amd import resolve_quartets as RQ
+    g = load_golden("tree_T12_S2000")
+    engine.set_data(g["tmparr"], g["tmpmap"])
+    _, _, flags = engine.resolve(g["quartets"], False)
+    assert (flags & 8).sum() == 0
+    try:
+        engine.set_option("svd_method", 1)
+        engine.set_option("bdsqr_maxit", 1)
+        _, _, flags = engine.resolve(g["quartets"], False)
+        assert (flags & 8).sum() > len(flags) // 2
+    finally:
+        engine.set_option("bdsqr_maxit", 0)
+    eng0 = RQ.get_engine(0)
+    try:
+        eng0.set_option("bdsqr_maxit", 1)
+        with pytest.raises(np.linalg.LinAlgError):
+            RQ.new_infer_resolved_quartets(g["tmparr"], g["tmpmap"], g["quartets"], False)
+    finally:
+        eng0.set_option("bdsqr_maxit", 0)
 
 
 @pytest.mark.parametrize("T,S,seed,p,missing,sub", [

@@ -1,10 +1,11 @@
 """The native text producers of the C ABI (tq_format_tsv / tq_format_qmc, host code) against the
 Python formulas of the reference: run_inference.py:233-234 (`to_csv(float_format='%.6f')`, i.e.
-`'%.6f' % x`) and :254-305 (`iter_qmc_formatted`, mirrored in tetrad_amd/qmc_format.py)."""
+`'%.6f' % x`) and :254-305 (`iter_qmc_formatted`, restated in oracle/qmc_format.py)."""
 import numpy as np
 import pytest
 
 from tetrad_amd import distributor as D
+from oracle import qmc_format as OQ
 from tetrad_amd import qmc_format as Q
 
 
@@ -56,7 +57,8 @@ def test_qmc_lines_match_file_based_mirror(tmp_path, weights, min_snps, min_rati
     sc[5::211, 0] = 0.0                    # a zero smallest score: ratio is defined as 1
     f = tmp_path / "q.tsv"
     f.write_text(_py_tsv(q, sc, st))
-    want = list(Q.iter_qmc_formatted(f, weights, min_snps, min_ratio))
+    want = list(OQ.iter_qmc_formatted(f, weights, min_snps, min_ratio))
+    assert list(Q.iter_qmc_formatted(f, weights, min_snps, min_ratio)) == want
     got = [b.decode() for b in Q.qmc_lines(q, sc, st, weights, min_snps, min_ratio)]
     assert got == want
 

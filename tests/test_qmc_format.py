@@ -1,5 +1,11 @@
-"""Host mirror of the wQMC line formatter (run_inference.py:254-305): hand-checked expectations."""
-from tetrad_amd.qmc_format import iter_qmc_formatted, write_qmc_format
+"""wQMC line formatter (run_inference.py:254-305): hand-checked expectations, for the oracle's
+restatement and for the product's native-backed functions of the same names."""
+import pytest
+
+from oracle import qmc_format as O
+from tetrad_amd import qmc_format as P
+
+MODS = [pytest.param(O, id="oracle"), pytest.param(P, id="native")]
 
 
 ROWS = [
@@ -11,7 +17,9 @@ ROWS = [
 ]
 
 
-def test_weight_strategies(tmp_path):
+@pytest.mark.parametrize("M", MODS)
+def test_weight_strategies(tmp_path, M):
+    iter_qmc_formatted = M.iter_qmc_formatted
     f = tmp_path / "q.tsv"
     f.write_text("".join(ROWS))
     # weights=0: unweighted, topology decides the split: 0 -> ab|cd, 1 -> ac|bd, 2 -> ad|bc
@@ -27,7 +35,9 @@ def test_weight_strategies(tmp_path):
     assert list(iter_qmc_formatted(f, 1, min_ratio=3.0)) == ["0,1|2,3:3.50000", "0,4|1,3:8.50000"]
 
 
-def test_write_is_a_seeded_permutation(tmp_path):
+@pytest.mark.parametrize("M", MODS)
+def test_write_is_a_seeded_permutation(tmp_path, M):
+    iter_qmc_formatted, write_qmc_format = M.iter_qmc_formatted, M.write_qmc_format
     f = tmp_path / "q.tsv"
     f.write_text("".join(ROWS * 50))
     write_qmc_format(f, tmp_path / "a.txt", weights=1, seed=1)

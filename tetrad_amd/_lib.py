@@ -22,14 +22,16 @@ ERR_NAMES = {
     -1: "TQ_ERR_INVALID_ARG", -2: "TQ_ERR_NO_DEVICE", -3: "TQ_ERR_HIP",
     -4: "TQ_ERR_NO_DATA", -5: "TQ_ERR_LOCUS_ORDER", -6: "TQ_ERR_OOM",
 }
-FLAG_ZERO_DATA, FLAG_DEGENERATE, FLAG_BAD_INDEX = 1, 2, 4
+FLAG_ZERO_DATA, FLAG_DEGENERATE, FLAG_BAD_INDEX, FLAG_NO_CONVERGENCE = 1, 2, 4, 8
 
 #: every symbol include/tetrad_hip.h declares (checked by tests/test_cabi_symbols.py)
 SYMBOLS = [
     "tq_create", "tq_destroy", "tq_last_error", "tq_set_data", "tq_resolve",
     "tq_set_source", "tq_bootstrap", "tq_get_data", "tq_data_shape",
+    "tq_host_alloc", "tq_host_free", "tq_resolve_to_host", "tq_scan_dev", "tq_svd_dev",
     "tq_resolve_dev", "tq_resolve_range_dev", "tq_unrank_dev", "tq_resolve_debug",
-    "tq_timing_enable", "tq_timing_read", "tq_timing_read_split", "tq_set_option", "tq_device_info", "tq_debug_fetch",
+    "tq_timing_enable", "tq_timing_read", "tq_timing_read_split", "tq_timing_read_kernels",
+    "tq_set_option", "tq_device_info", "tq_debug_fetch",
     "tq_format_tsv", "tq_format_qmc",
 ]
 
@@ -94,6 +96,18 @@ def load() -> ctypes.CDLL:
     lib.tq_data_shape.restype = i32
     lib.tq_resolve.argtypes = [vp, vp, i64, i32, vp, vp, vp]
     lib.tq_resolve.restype = i32
+    lib.tq_host_alloc.argtypes = [i64, c.POINTER(vp)]
+    lib.tq_host_alloc.restype = i32
+    lib.tq_host_free.argtypes = [vp]
+    lib.tq_host_free.restype = i32
+    lib.tq_resolve_to_host.argtypes = [vp, vp, i64, i32, vp, vp, vp]
+    lib.tq_resolve_to_host.restype = i32
+    lib.tq_scan_dev.argtypes = [vp, vp, i64, i32, vp]
+    lib.tq_scan_dev.restype = i32
+    lib.tq_svd_dev.argtypes = [vp, i64, i64, vp, vp, vp, vp]
+    lib.tq_svd_dev.restype = i32
+    lib.tq_timing_read_kernels.argtypes = [vp, c.POINTER(c.c_double), i32, c.POINTER(i64)]
+    lib.tq_timing_read_kernels.restype = i32
     lib.tq_resolve_dev.argtypes = [vp, vp, i64, i32, vp, vp, vp, vp]
     lib.tq_resolve_dev.restype = i32
     lib.tq_resolve_range_dev.argtypes = [vp, c.c_uint64, i64, i32, vp, vp, vp, vp, vp]

@@ -201,7 +201,7 @@ __device__ __forceinline__ double hypot_nr(double a, double b) { return sqrt_nr(
 constexpr int RSQ_NR = 1;      // Newton steps on v_rsq_f64 inside a rotation (1: 5e-15, 2: 1e-16 relative)
 
 __global__ void __launch_bounds__(WAVE)
-tq_bdsqr_kernel(const double *__restrict__ de, int64_t nmat, double *__restrict__ sv)
+tq_bdsqr_kernel(const double *__restrict__ de, int64_t nmat, double *__restrict__ sv, int maxit)
 {
     __shared__ double lds[32 * WAVE];
     const int lane = threadIdx.x;
@@ -237,6 +237,7 @@ tq_bdsqr_kernel(const double *__restrict__ de, int64_t nmat, double *__restrict_
         // loop that touches registers only, so a lane never spends a whole sweep slot of the wave on
         // "k--" while its neighbours sweep.
         int k = 15, its = 0, l = 0;
+        bool noconv = false;
         for (;;) {
             for (;;) {
                 // split point l = largest l <= k with e[l] negligible (or l == 0), unless a negligible
@@ -259,8 +260,11 @@ tq_bdsqr_kernel(const double *__restrict__ de, int64_t nmat, double *__restrict_
                         ss = -f * hi;
                     }
                 }
-                if (l != k && its < 60) break;      // a block of >= 2 values that still needs sweeps
-                if (--k < 0) break;                 // converged (or iteration cap: keep what we have)
+                if (l != k) {
+                    if (its < maxit) break;         // a block of >= 2 values that still needs sweeps
+                    noconv = true;                  // iteration cap: keep what we have, but say so
+                }
+                if (--k < 0) break;                 // converged
                 its = 0;
             }
             if (k < 0) break;
@@ -314,7 +318,12 @@ tq_bdsqr_kernel(const double *__restrict__ de, int64_t nmat, double *__restrict_
 #undef SET_W
         if (live) {
 #pragma unroll
-            for (int i = 0; i < 16; ++i) sv[m * 16 + i] = fabs(W_(i));
+            for (int i = 0; i < 16; ++i) {
+                // a matrix that hit the sweep cap hands its values over with the sign bit set (also on
+                // zeros): tq_score_kernel turns that into TQ_FLAG_NO_CONVERGENCE (numpy raises LinAlgError)
+                const double v = fabs(W_(i));
+                sv[m * 16 + i] = noconv ? -v : v;
+            }
         }
     }
 }
@@ -332,11 +341,16 @@ tq_score_kernel(const double *__restrict__ sv, const uint32_t *__restrict__ nsnp
     double sc2[3][16];
     int rnk[3];
     double smax_all = 0.0;
+    int noconv = 0;
 #pragma unroll
     for (int t = 0; t < 3; ++t) {
         double s[16];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) s[i] = sv[(q * 3 + t) * 16 + i];
+        for (int i = 0; i < 16; ++i) {
+            const double v = sv[(q * 3 + t) * 16 + i];
+            noconv |= __double2hiint(v) < 0;                 // sign bit: tq_bdsqr_kernel's "not converged"
+            s[i] = fabs(v);
+        }
         // bitonic sorting network, descending (static indices only)
 #pragma unroll
         for (int k = 2; k <= 16; k <<= 1) {
@@ -386,6 +400,7 @@ tq_score_kernel(const double *__restrict__ sv, const uint32_t *__restrict__ nsnp
     const double lo2 = (topo == 0) ? fmin(sc[1], sc[2]) : (topo == 1) ? fmin(sc[0], sc[2]) : fmin(sc[0], sc[1]);
     uint32_t fl = 0;
     if ((lo2 - lo1) <= DEGENERATE_REL_GAP * smax_all) fl |= TQ_FLAG_DEGENERATE;
+    if (noconv) fl |= TQ_FLAG_NO_CONVERGENCE;
     const uint32_t nsn = nsnps_in[q];
     if (nsn == 0) {
         topo = 0;

@@ -74,6 +74,7 @@ struct SvResult {
     int pos;        // its 0-based position in descending order
     int rank;       // numpy.linalg.matrix_rank rule on the group's 16 values
     double smax;
+    bool noconv;    // the sweep cap was reached with rotations still pending
 };
 
 // f64 reciprocal / reciprocal square root from the hardware estimate (v_rcp_f64 / v_rsq_f64)
@@ -177,6 +178,7 @@ __device__ __forceinline__ SvResult jacobi16(double (&a)[16], int j, int lane)
 #pragma unroll
     for (int r = 0; r < 16; ++r) nrm = fma(a[r], a[r], nrm);
     SvResult o;
+    o.noconv = active;      // the loop ends early (break) once no group of the wave is active
     o.sigma = sqrt(nrm);
     o.smax = group_max(o.sigma);
     int pos = 0;
@@ -236,6 +238,7 @@ tq_svd_kernel(const uint32_t *__restrict__ cm, const uint32_t *__restrict__ quar
         double sig[3];
         int pos[3], rnk[3];
         double smax_all = 0.0;
+        bool noconv = false;
         uint32_t my_nsnps = 0;
 #pragma unroll
         for (int t = 0; t < 3; ++t) {
@@ -260,6 +263,7 @@ tq_svd_kernel(const uint32_t *__restrict__ cm, const uint32_t *__restrict__ quar
             pos[t] = sv.pos;
             rnk[t] = sv.rank;
             smax_all = fmax(smax_all, sv.smax);
+            noconv |= sv.noconv;
             if (DEBUG) {
                 if (out.svds && myq < Q) out.svds[(myq * 3 + t) * 16 + sv.pos] = sv.sigma;
                 if (out.ranks && myq < Q && j == 0) out.ranks[myq * 3 + t] = sv.rank;
@@ -284,6 +288,7 @@ tq_svd_kernel(const uint32_t *__restrict__ cm, const uint32_t *__restrict__ quar
             const double lo2 = (topo == 0) ? fmin(sc[1], sc[2]) : (topo == 1) ? fmin(sc[0], sc[2]) : fmin(sc[0], sc[1]);
             uint32_t fl = 0;
             if ((lo2 - lo1) <= DEGENERATE_REL_GAP * smax_all) fl |= TQ_FLAG_DEGENERATE;
+            if (noconv) fl |= TQ_FLAG_NO_CONVERGENCE;
             if (my_nsnps == 0) {                 // resolve_quartets.py:230-232
                 topo = 0;
                 sc[0] = sc[1] = sc[2] = 0.001;

@@ -37,6 +37,8 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <map>
+#include <mutex>
 #include <new>
 #include <string>
 #include <unordered_set>
@@ -59,6 +61,8 @@ namespace {
 // ======================================================================================
 // host side: context + C ABI
 // ======================================================================================
+enum { TAG_ORIGIN = -1, TAG_ORDER = 0, TAG_SCAN = 1, TAG_BIDIAG = 2, TAG_BDSQR = 3, TAG_SCORE = 4, TAG_COUNT = 5 };
+
 struct tq_ctx {
     int device = 0;
     std::string err;
@@ -84,45 +88,44 @@ struct tq_ctx {
     size_t boot_tmp_bytes = 0;
     // scratch for the host-buffer API
     void *d_scratch = nullptr;
-    void *h_stage = nullptr;        // pinned staging for small host-buffer calls
-    size_t stage_bytes = 0;
     size_t scratch_bytes = 0;
-    // count-matrix slab between the two kernels: u32 [batch][256]
+    // count slab between the scan and the singular-value stage: u32 [batch][256]; ordering scratch
     uint32_t *d_cm = nullptr;
     int64_t cm_quartets = 0;
-    int cm_slabs = 0;
-    // (a,b)-sorted processing order of the current batch: keys/idx in, keys/idx out, cub temp
-    uint32_t *d_sort = nullptr;     // 4 arrays of cm_quartets u32
+    uint32_t *d_sort = nullptr;     // 4 arrays of cm_quartets u32: keys/idx in, keys/idx out
     void *d_sort_tmp = nullptr;
     size_t sort_tmp_bytes = 0;
-    int order = 1;                  // 1 = process quartets in (a,b)-sorted order
-    // HQR path scratch: de f64[3*batch][32], sv f64[3*batch][16], nsnps u32[batch]
+    int order = 1;                  // 1 = process quartets in (a,b,c)-sorted order
+    // singular-value stage scratch, sized for one chunk of `svd_chunk` quartets and re-used chunk after
+    // chunk (so the bidiagonals / values of a chunk stay in the Infinity Cache between its three kernels):
+    // de f64[3*chunk][32], sv f64[3*chunk][16], nsnps u32[chunk]
     double *d_de = nullptr, *d_sv = nullptr;
     uint32_t *d_nsnps = nullptr;
+    int64_t svd_quartets = 0;
+    int64_t svd_chunk = 1 << 17;    // quartets per pass of the singular-value stage (and per result D2H piece)
     int svd_method = 1;             // 0 = one-sided Jacobi (tq_svd_kernel), 1 = Householder + bidiagonal QR
+    int bdsqr_maxit = 60;           // QR sweeps per singular value before a matrix is declared not converged
     int scan_wg = 4;                // waves per workgroup of the cooperative scan kernel (1 = one wave per quartet)
-    // software pipeline across sub-batches: scan of sub-batch i+1 runs on a second stream beside the
-    // singular-value stage of sub-batch i (0 = off: one stage after the other on the caller's stream)
-    int64_t overlap = 0;            // sub-batch size in quartets
-    bool input_sorted = false;      // set by the host-buffer entry points when the quartets already are in key order
     int xcd_remap = 1;              // 1: scan workgroups of one XCD take a contiguous part of the sorted order
     int svd_wpc = 0;                // blocks per CU of the bidiag / bdsqr grids (0 = one pass per block)
-    int ov_scan_wgs = 1;            // scan workgroups per CU while overlapping
-    int ov_svd_waves = 6;           // singular-value-stage waves per CU while overlapping
-    hipStream_t sA = nullptr, sB = nullptr;
-    hipEvent_t evIn = nullptr, evA[2] = {nullptr, nullptr}, evB[2] = {nullptr, nullptr}, evEndA = nullptr, evEndB = nullptr;
-    int wpc_override = 0;           // transient: grid_for() uses this instead of waves_per_cu when > 0
+    // what tq_scan_dev left in the count slab (consumed by tq_svd_dev)
+    const uint32_t *scanned_q = nullptr;
+    int64_t scanned_Q = 0;
+    // host-buffer API: own compute and copy streams, events for the D2H pipeline
+    hipStream_t sK = nullptr, sC = nullptr;
+    std::vector<hipEvent_t> pipe_events;
     // options
     int nrep = 1;
     int waves_per_cu = 0;           // 0 = from the occupancy query
     int phases = 3;                 // diagnostics only: 1 = scan kernel only, 2 = SVD kernel only
     int scan_method = -1;           // 0 = EXEC-masked slot per site, 1 = set-bit walk, -1 = 1 if subsample else 0
-    int64_t batch = 1 << 23;        // quartets per scan->svd batch (<= 8 GiB count slab + 9 GiB bidiagonals / values)
-    // timing: per resolve call one (start, mid, stop) triple per batch
+    int64_t batch = 1 << 23;        // quartets per scan batch (8 GiB count slab)
+    // timing: a sequence of tagged HIP events on the launch stream; the time between two consecutive
+    // marks is attributed to the tag of the later one (TAG_ORIGIN starts a sequence)
     bool timing = false;
-    struct Ev { hipEvent_t e0, e1, e2; };
-    std::vector<Ev> events;
-    size_t events_used = 0;
+    struct Mark { int tag; hipEvent_t ev; };
+    std::vector<Mark> marks;
+    std::vector<hipEvent_t> event_pool;
     int64_t timed_calls = 0;
 };
 
@@ -137,7 +140,10 @@ int fail(tq_ctx *ctx, int code, const char *fmt, ...)
     va_start(ap, fmt);
     vsnprintf(buf, sizeof buf, fmt, ap);
     va_end(ap);
-    if (ctx) ctx->err = buf; else g_create_err = buf;
+    try {
+        if (ctx) ctx->err = buf; else g_create_err = buf;
+    } catch (...) {
+    }
     return code;
 }
 
@@ -148,6 +154,97 @@ int fail(tq_ctx *ctx, int code, const char *fmt, ...)
             return fail(ctx, e_ == hipErrorOutOfMemory ? TQ_ERR_OOM : TQ_ERR_HIP, "%s failed: %s", \
                         #call, hipGetErrorString(e_));                                        \
     } while (0)
+
+// ---------------------------------------------------------------------------------------------
+// Pinned host memory pool (process-wide: blocks handed to a caller may outlive any context).
+// Result arrays that live in such a block are written by the copy engine directly (no staging, no
+// host pass); blocks are recycled because pinning pages costs about as much as a resolve call.
+// ---------------------------------------------------------------------------------------------
+struct PinnedPool {
+    std::mutex mu;
+    std::map<uintptr_t, size_t> live;              // base -> bytes of blocks handed out
+    std::multimap<size_t, void *> idle;            // bytes -> base of cached blocks
+    size_t idle_bytes = 0;
+    static constexpr size_t IDLE_CAP = (size_t)4 << 30;
+    static size_t round_up(size_t b)
+    {
+        size_t g = (size_t)1 << 16;
+        while (g < b && g < ((size_t)1 << 24)) g <<= 1;         // 64 KiB .. 16 MiB: powers of two
+        if (g >= b) return g;
+        const size_t step = (size_t)1 << 24;                   // beyond: multiples of 16 MiB
+        return (b + step - 1) / step * step;
+    }
+    int alloc(size_t bytes, void **out)
+    {
+        const size_t want = round_up(bytes ? bytes : 1);
+        std::lock_guard<std::mutex> g(mu);
+        try {
+            auto it = idle.lower_bound(want);
+            if (it != idle.end() && it->first <= want * 2) {
+                void *p = it->second;
+                const size_t sz = it->first;
+                idle.erase(it);
+                idle_bytes -= sz;
+                live[(uintptr_t)p] = sz;
+                *out = p;
+                return TQ_OK;
+            }
+            void *p = nullptr;
+            if (hipHostMalloc(&p, want, hipHostMallocPortable) != hipSuccess || !p) return TQ_ERR_OOM;
+            live[(uintptr_t)p] = want;
+            *out = p;
+            return TQ_OK;
+        } catch (...) {
+            return TQ_ERR_OOM;
+        }
+    }
+    int release(void *p)
+    {
+        std::lock_guard<std::mutex> g(mu);
+        auto it = live.find((uintptr_t)p);
+        if (it == live.end()) return TQ_ERR_INVALID_ARG;
+        const size_t sz = it->second;
+        live.erase(it);
+        bool cached = false;
+        if (idle_bytes + sz <= IDLE_CAP) {
+            try {
+                idle.emplace(sz, p);
+                idle_bytes += sz;
+                cached = true;
+            } catch (...) {
+            }
+        }
+        if (!cached) (void)hipHostFree(p);
+        return TQ_OK;
+    }
+    bool owns(const void *p, size_t bytes)
+    {
+        std::lock_guard<std::mutex> g(mu);
+        auto it = live.upper_bound((uintptr_t)p);
+        if (it == live.begin()) return false;
+        --it;
+        return (uintptr_t)p + bytes <= it->first + it->second;
+    }
+};
+
+PinnedPool &pool()
+{
+    static PinnedPool *p = new PinnedPool();       // never destroyed: blocks may be alive at exit
+    return *p;
+}
+
+// true when [p, p+bytes) is page-locked memory the copy engine can write asynchronously
+bool is_pinned(const void *p, size_t bytes)
+{
+    if (!p) return false;
+    if (pool().owns(p, bytes)) return true;
+    hipPointerAttribute_t a{};
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) {
+        (void)hipGetLastError();                               // unregistered memory: clear the sticky error
+        return false;
+    }
+    return a.type == hipMemoryTypeHost;
+}
 
 void free_data(tq_ctx *ctx)
 {
@@ -161,6 +258,7 @@ void free_data(tq_ctx *ctx)
     ctx->d_planes3 = nullptr;
     ctx->have_data = false;
     ctx->data_capacity = 0;
+    ctx->scanned_Q = 0;
 }
 
 void free_source(tq_ctx *ctx)
@@ -190,39 +288,19 @@ int ensure_scratch(tq_ctx *ctx, size_t bytes)
     return TQ_OK;
 }
 
-int ensure_stage(tq_ctx *ctx, size_t bytes)
+// count slab + ordering scratch for a scan batch of `quartets`
+int ensure_cm(tq_ctx *ctx, int64_t quartets)
 {
-    if (bytes <= ctx->stage_bytes) return TQ_OK;
-    if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
-    ctx->h_stage = nullptr;
-    ctx->stage_bytes = 0;
-    TQ_HIP(ctx, hipHostMalloc(&ctx->h_stage, bytes, hipHostMallocDefault));
-    ctx->stage_bytes = bytes;
-    return TQ_OK;
-}
-
-int ensure_cm(tq_ctx *ctx, int64_t quartets, int slabs = 1)
-{
-    if (quartets <= ctx->cm_quartets && slabs <= ctx->cm_slabs) return TQ_OK;
-    if (quartets < ctx->cm_quartets) quartets = ctx->cm_quartets;
-    if (slabs < ctx->cm_slabs) slabs = ctx->cm_slabs;
+    if (quartets <= ctx->cm_quartets) return TQ_OK;
     if (ctx->d_cm) (void)hipFree(ctx->d_cm);
     if (ctx->d_sort) (void)hipFree(ctx->d_sort);
     if (ctx->d_sort_tmp) (void)hipFree(ctx->d_sort_tmp);
-    if (ctx->d_de) (void)hipFree(ctx->d_de);
-    if (ctx->d_sv) (void)hipFree(ctx->d_sv);
-    if (ctx->d_nsnps) (void)hipFree(ctx->d_nsnps);
     ctx->d_cm = nullptr;
     ctx->d_sort = nullptr;
     ctx->d_sort_tmp = nullptr;
-    ctx->d_de = ctx->d_sv = nullptr;
-    ctx->d_nsnps = nullptr;
     ctx->cm_quartets = 0;
-    ctx->cm_slabs = 0;
-    TQ_HIP(ctx, hipMalloc((void **)&ctx->d_cm, (size_t)quartets * 1024 * (size_t)slabs));   // second slab: overlap mode only
-    TQ_HIP(ctx, hipMalloc((void **)&ctx->d_de, (size_t)quartets * 3 * 32 * sizeof(double)));
-    TQ_HIP(ctx, hipMalloc((void **)&ctx->d_sv, (size_t)quartets * 3 * 16 * sizeof(double)));
-    TQ_HIP(ctx, hipMalloc((void **)&ctx->d_nsnps, (size_t)quartets * sizeof(uint32_t)));
+    ctx->scanned_Q = 0;
+    TQ_HIP(ctx, hipMalloc((void **)&ctx->d_cm, (size_t)quartets * 1024));
     TQ_HIP(ctx, hipMalloc((void **)&ctx->d_sort, (size_t)quartets * 16));
     size_t tmp = 0;
     uint32_t *k = ctx->d_sort;
@@ -230,15 +308,53 @@ int ensure_cm(tq_ctx *ctx, int64_t quartets, int slabs = 1)
     TQ_HIP(ctx, hipMalloc(&ctx->d_sort_tmp, tmp ? tmp : 16));
     ctx->sort_tmp_bytes = tmp;
     ctx->cm_quartets = quartets;
-    ctx->cm_slabs = slabs;
     return TQ_OK;
 }
 
-// order[] for one batch: indices sorted by (first taxon, second taxon); nullptr = natural order
-int make_order(tq_ctx *ctx, const uint32_t *dq, int64_t n, hipStream_t stream, const uint32_t **order)
+// scratch of the singular-value stage for one chunk of `quartets`
+int ensure_svd(tq_ctx *ctx, int64_t quartets)
+{
+    if (quartets <= ctx->svd_quartets) return TQ_OK;
+    if (ctx->d_de) (void)hipFree(ctx->d_de);
+    if (ctx->d_sv) (void)hipFree(ctx->d_sv);
+    if (ctx->d_nsnps) (void)hipFree(ctx->d_nsnps);
+    ctx->d_de = ctx->d_sv = nullptr;
+    ctx->d_nsnps = nullptr;
+    ctx->svd_quartets = 0;
+    TQ_HIP(ctx, hipMalloc((void **)&ctx->d_de, (size_t)quartets * 3 * 32 * sizeof(double)));
+    TQ_HIP(ctx, hipMalloc((void **)&ctx->d_sv, (size_t)quartets * 3 * 16 * sizeof(double)));
+    TQ_HIP(ctx, hipMalloc((void **)&ctx->d_nsnps, (size_t)quartets * sizeof(uint32_t)));
+    ctx->svd_quartets = quartets;
+    return TQ_OK;
+}
+
+// ---- timing marks -------------------------------------------------------------------------------
+int mark(tq_ctx *ctx, int tag, hipStream_t stream)
+{
+    if (!ctx->timing) return TQ_OK;
+    hipEvent_t ev;
+    if (!ctx->event_pool.empty()) {
+        ev = ctx->event_pool.back();
+        ctx->event_pool.pop_back();
+    } else {
+        TQ_HIP(ctx, hipEventCreate(&ev));
+    }
+    try {
+        ctx->marks.push_back({tag, ev});
+    } catch (...) {
+        (void)hipEventDestroy(ev);
+        return fail(ctx, TQ_ERR_OOM, "out of host memory");
+    }
+    TQ_HIP(ctx, hipEventRecord(ev, stream));
+    return TQ_OK;
+}
+
+// order[] for one batch: indices sorted by (first, second[, third]) taxon; nullptr = natural order
+int make_order(tq_ctx *ctx, const uint32_t *dq, int64_t n, bool input_sorted, hipStream_t stream,
+               const uint32_t **order)
 {
     *order = nullptr;
-    if (!ctx->order || n < 1024 || ctx->T > 65535 || ctx->input_sorted) return TQ_OK;
+    if (!ctx->order || n < 1024 || ctx->T > 65535 || input_sorted) return TQ_OK;
     uint32_t *keys_in = ctx->d_sort, *idx_in = keys_in + ctx->cm_quartets;
     uint32_t *keys_out = idx_in + ctx->cm_quartets, *idx_out = keys_out + ctx->cm_quartets;
     const uint64_t T = (uint64_t)ctx->T;
@@ -271,12 +387,10 @@ DevData dev_data(const tq_ctx *ctx)
     return d;
 }
 
-constexpr size_t STAGE_LIMIT = 2u << 20;     // bytes of quartets + results that go through pinned staging
-
 template <typename K>
 int grid_for(tq_ctx *ctx, K kern, int64_t items, int64_t *grid, int wpc_kernel = 0)
 {
-    int wpc = wpc_kernel > 0 ? wpc_kernel : ctx->wpc_override > 0 ? ctx->wpc_override : ctx->waves_per_cu;
+    int wpc = wpc_kernel > 0 ? wpc_kernel : ctx->waves_per_cu;
     if (wpc <= 0) {
         int nb = 0;
         TQ_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, WAVE, 0));
@@ -305,8 +419,7 @@ template <bool SUB, int METHOD, int NW>
 int launch_scan_wg(tq_ctx *ctx, const uint32_t *dq, const uint32_t *order, int64_t Q, hipStream_t stream)
 {
     auto kern = tq_scan_wg_kernel<SUB, METHOD, NW>;
-    int wgs = ctx->wpc_override > 0 ? (ctx->wpc_override + NW - 1) / NW
-              : ctx->waves_per_cu > 0 ? (ctx->waves_per_cu + NW - 1) / NW : 0;
+    const int wgs = ctx->waves_per_cu > 0 ? (ctx->waves_per_cu + NW - 1) / NW : 0;
     // default: one block of NW quartets per workgroup, dispatched in sorted order.  Workgroups that
     // run at the same time are then neighbours of the (a,b) order (their shared rows are L2 hits) and
     // the dispatcher balances the load; a persistent grid-stride loop was 13 % slower.
@@ -368,42 +481,44 @@ int launch_scan_n(tq_ctx *ctx, const uint32_t *dq, const uint32_t *order, int64_
 #undef TQ_SCAN_CASE
 }
 
+// Jacobi path: count slab rows [cm, cm + n) -> outputs of the same rows
 template <bool DEBUG>
-int launch_svd(tq_ctx *ctx, const uint32_t *dq, int64_t Q, const OutPtrs &out, hipStream_t stream)
+int launch_svd(tq_ctx *ctx, const uint32_t *cm, const uint32_t *dq, int64_t n, const OutPtrs &out, hipStream_t stream)
 {
     auto kern = tq_svd_kernel<DEBUG>;
     int64_t grid;
-    int rc = grid_for(ctx, kern, (Q + QPW - 1) / QPW, &grid);
+    int rc = grid_for(ctx, kern, (n + QPW - 1) / QPW, &grid);
     if (rc) return rc;
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(WAVE), 0, stream, (const uint32_t *)ctx->d_cm, dq, Q,
-                       (int32_t)ctx->T, out);
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(WAVE), 0, stream, cm, dq, n, (int32_t)ctx->T, out);
     TQ_HIP(ctx, hipGetLastError());
-    return TQ_OK;
+    return mark(ctx, TAG_BIDIAG, stream);
 }
 
+// Householder + QR path, one chunk (n <= svd scratch)
 template <bool DEBUG>
-int launch_hqr(tq_ctx *ctx, const uint32_t *dq, int64_t Q, const OutPtrs &out, hipStream_t stream)
+int launch_hqr(tq_ctx *ctx, const uint32_t *cm, const uint32_t *dq, int64_t n, const OutPtrs &out, hipStream_t stream)
 {
     int64_t grid;
     auto k1 = tq_bidiag_kernel<DEBUG>;
     // one pass per block unless told otherwise: the work per pass varies (QR iterations), and the
     // hardware dispatcher balances it better than a static grid-stride loop (3.8 ms vs 5.1 ms per 1e6)
     const int svd_wpc = ctx->svd_wpc > 0 ? ctx->svd_wpc : (1 << 20);
-    int rc = grid_for(ctx, k1, (Q + 15) / 16, &grid, svd_wpc);
+    int rc = grid_for(ctx, k1, (n + 15) / 16, &grid, svd_wpc);
     if (rc) return rc;
-    hipLaunchKernelGGL(k1, dim3((unsigned)grid), dim3(WAVE), 0, stream, (const uint32_t *)ctx->d_cm, Q, ctx->d_de,
-                       ctx->d_nsnps, out.cmats);
+    hipLaunchKernelGGL(k1, dim3((unsigned)grid), dim3(WAVE), 0, stream, cm, n, ctx->d_de, ctx->d_nsnps, out.cmats);
     TQ_HIP(ctx, hipGetLastError());
-    const int64_t nmat = 3 * Q;
+    if ((rc = mark(ctx, TAG_BIDIAG, stream))) return rc;
+    const int64_t nmat = 3 * n;
     rc = grid_for(ctx, tq_bdsqr_kernel, (nmat + WAVE - 1) / WAVE, &grid, svd_wpc);
     if (rc) return rc;
     hipLaunchKernelGGL(tq_bdsqr_kernel, dim3((unsigned)grid), dim3(WAVE), 0, stream, (const double *)ctx->d_de, nmat,
-                       ctx->d_sv);
+                       ctx->d_sv, ctx->bdsqr_maxit);
     TQ_HIP(ctx, hipGetLastError());
-    hipLaunchKernelGGL(tq_score_kernel<DEBUG>, dim3((unsigned)((Q + 255) / 256)), dim3(256), 0, stream,
-                       (const double *)ctx->d_sv, (const uint32_t *)ctx->d_nsnps, dq, Q, (int32_t)ctx->T, out);
+    if ((rc = mark(ctx, TAG_BDSQR, stream))) return rc;
+    hipLaunchKernelGGL(tq_score_kernel<DEBUG>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream,
+                       (const double *)ctx->d_sv, (const uint32_t *)ctx->d_nsnps, dq, n, (int32_t)ctx->T, out);
     TQ_HIP(ctx, hipGetLastError());
-    return TQ_OK;
+    return mark(ctx, TAG_SCORE, stream);
 }
 
 OutPtrs offset_out(const OutPtrs &o, int64_t q0)
@@ -418,137 +533,242 @@ OutPtrs offset_out(const OutPtrs &o, int64_t q0)
     return r;
 }
 
-int launch_overlapped(tq_ctx *ctx, const uint32_t *dq, int64_t Q, int subsample, const OutPtrs &out,
-                      hipStream_t stream);
-
-// scan kernel -> cm slab -> SVD kernel, in batches so that the slab stays <= batch KiB
-int launch(tq_ctx *ctx, const uint32_t *dq, int64_t Q, int subsample, bool debug, const OutPtrs &out,
-           hipStream_t stream)
+int check_ready(tq_ctx *ctx, int subsample)
 {
     if (!ctx->have_data) return fail(ctx, TQ_ERR_NO_DATA, "tq_set_data has not been called");
     if (subsample && !ctx->locus_runs_ok)
         return fail(ctx, TQ_ERR_LOCUS_ORDER,
                     "subsample mode needs each locus id in one contiguous run of sites (and no id 0xFFFFFFFF)");
-    if (Q == 0) return TQ_OK;
-    if (ctx->overlap > 0 && !debug && ctx->phases == 3 && Q > ctx->overlap)
-        return launch_overlapped(ctx, dq, Q, subsample, out, stream);
-    const int64_t batch = Q < ctx->batch ? Q : ctx->batch;
-    int rc = ensure_cm(ctx, batch);
+    return TQ_OK;
+}
+
+// Stage 1 of a pass: ordering + site scan of quartets dq[0..n) into the count slab (n <= ctx->batch).
+int stage_scan(tq_ctx *ctx, const uint32_t *dq, int64_t n, int subsample, bool input_sorted, hipStream_t stream)
+{
+    int rc = ensure_cm(ctx, n);
     if (rc) return rc;
-    if (ctx->timing) ctx->timed_calls++;
-    for (int64_t q0 = 0; q0 < Q; q0 += batch) {
-        const int64_t n = (Q - q0) < batch ? (Q - q0) : batch;
-        tq_ctx::Ev ev{};
-        if (ctx->timing) {
-            if (ctx->events_used == ctx->events.size()) {
-                tq_ctx::Ev e{};
-                TQ_HIP(ctx, hipEventCreate(&e.e0));
-                TQ_HIP(ctx, hipEventCreate(&e.e1));
-                TQ_HIP(ctx, hipEventCreate(&e.e2));
-                ctx->events.push_back(e);
-            }
-            ev = ctx->events[ctx->events_used++];
-            TQ_HIP(ctx, hipEventRecord(ev.e0, stream));
-        }
-        if (ctx->phases & 1) {
-            const uint32_t *order = nullptr;
-            rc = make_order(ctx, dq + q0 * 4, n, stream, &order);
-            if (rc) return rc;
-            rc = launch_scan_n(ctx, dq + q0 * 4, order, n, subsample, stream);
-            if (rc) return rc;
-        }
-        if (ctx->timing) TQ_HIP(ctx, hipEventRecord(ev.e1, stream));
+    ctx->scanned_Q = 0;
+    if ((rc = mark(ctx, TAG_ORIGIN, stream))) return rc;
+    if (ctx->phases & 1) {
+        const uint32_t *order = nullptr;
+        rc = make_order(ctx, dq, n, input_sorted, stream, &order);
+        if (rc) return rc;
+        if ((rc = mark(ctx, TAG_ORDER, stream))) return rc;
+        rc = launch_scan_n(ctx, dq, order, n, subsample, stream);
+        if (rc) return rc;
+        if ((rc = mark(ctx, TAG_SCAN, stream))) return rc;
+    }
+    ctx->scanned_q = dq;
+    ctx->scanned_Q = n;
+    return TQ_OK;
+}
+
+// Stage 2 of a pass: singular values, ranks, scores and topology of rows [q0, q0+n) of the scanned
+// batch, in chunks of svd_chunk quartets.  `out` points at the outputs of row q0.  After each chunk
+// `after_chunk(c0, cn)` is called (c0 relative to q0) with the chunk's kernels enqueued: the host-buffer
+// API starts that chunk's result D2H there.
+template <typename F>
+int stage_svd(tq_ctx *ctx, int64_t q0, int64_t n, bool debug, const OutPtrs &out, hipStream_t stream, F &&after_chunk)
+{
+    if (q0 < 0 || n < 0 || q0 + n > ctx->scanned_Q)
+        return fail(ctx, TQ_ERR_INVALID_ARG, "rows [%lld,+%lld) are outside the scanned batch of %lld quartets",
+                    (long long)q0, (long long)n, (long long)ctx->scanned_Q);
+    const int64_t chunk = ctx->svd_chunk < n ? ctx->svd_chunk : n;
+    int rc = ctx->svd_method == 1 ? ensure_svd(ctx, chunk) : TQ_OK;
+    if (rc) return rc;
+    for (int64_t c0 = 0; c0 < n; c0 += chunk) {
+        const int64_t cn = (n - c0) < chunk ? (n - c0) : chunk;
         if (ctx->phases & 2) {
-            const OutPtrs o = offset_out(out, q0);
+            const uint32_t *cm = ctx->d_cm + (size_t)(q0 + c0) * 256;
+            const uint32_t *dq = ctx->scanned_q + (q0 + c0) * 4;
+            const OutPtrs o = offset_out(out, c0);
+            if ((rc = mark(ctx, TAG_ORIGIN, stream))) return rc;
             if (ctx->svd_method == 0)
-                rc = debug ? launch_svd<true>(ctx, dq + q0 * 4, n, o, stream)
-                           : launch_svd<false>(ctx, dq + q0 * 4, n, o, stream);
+                rc = debug ? launch_svd<true>(ctx, cm, dq, cn, o, stream) : launch_svd<false>(ctx, cm, dq, cn, o, stream);
             else
-                rc = debug ? launch_hqr<true>(ctx, dq + q0 * 4, n, o, stream)
-                           : launch_hqr<false>(ctx, dq + q0 * 4, n, o, stream);
+                rc = debug ? launch_hqr<true>(ctx, cm, dq, cn, o, stream) : launch_hqr<false>(ctx, cm, dq, cn, o, stream);
             if (rc) return rc;
         }
-        if (ctx->timing) TQ_HIP(ctx, hipEventRecord(ev.e2, stream));
+        if ((rc = after_chunk(c0, cn))) return rc;
     }
     return TQ_OK;
 }
 
-// Overlapped form of launch(): the batch is cut into sub-batches; scan(i+1) runs on stream A beside
-// the singular-value stage of sub-batch i on stream B (two count slabs).  Both grids are sized to a
-// fraction of each CU so that the two stages are co-resident: the scan is an L2/LDS/integer mix at
-// ~50 % VALU, the bidiagonal QR a latency-bound f64 chain at ~40 % -- they fill each other's gaps.
-int launch_overlapped(tq_ctx *ctx, const uint32_t *dq, int64_t Q, int subsample, const OutPtrs &out,
-                      hipStream_t stream)
+struct NoChunkHook {
+    int operator()(int64_t, int64_t) const { return TQ_OK; }
+};
+
+// One pass of the path over quartets dq[0..Q) with device outputs: scan batches of <= ctx->batch quartets,
+// each followed by its singular-value stage.
+template <typename F>
+int launch(tq_ctx *ctx, const uint32_t *dq, int64_t Q, int subsample, bool debug, bool input_sorted,
+           const OutPtrs &out, hipStream_t stream, F &&after_chunk)
 {
-    const int64_t sub = ctx->overlap;
-    int rc = ensure_cm(ctx, sub, 2);
+    int rc = check_ready(ctx, subsample);
     if (rc) return rc;
-    if (!ctx->sA) {
-        TQ_HIP(ctx, hipStreamCreateWithFlags(&ctx->sA, hipStreamNonBlocking));
-        TQ_HIP(ctx, hipStreamCreateWithFlags(&ctx->sB, hipStreamNonBlocking));
-        TQ_HIP(ctx, hipEventCreateWithFlags(&ctx->evIn, hipEventDisableTiming));
-        TQ_HIP(ctx, hipEventCreateWithFlags(&ctx->evEndA, hipEventDisableTiming));
-        TQ_HIP(ctx, hipEventCreateWithFlags(&ctx->evEndB, hipEventDisableTiming));
-        for (int i = 0; i < 2; ++i) {
-            TQ_HIP(ctx, hipEventCreateWithFlags(&ctx->evA[i], hipEventDisableTiming));
-            TQ_HIP(ctx, hipEventCreateWithFlags(&ctx->evB[i], hipEventDisableTiming));
-        }
+    if (Q == 0) return TQ_OK;
+    if (ctx->timing) ctx->timed_calls++;
+    const int64_t batch = Q < ctx->batch ? Q : ctx->batch;
+    for (int64_t q0 = 0; q0 < Q; q0 += batch) {
+        const int64_t n = (Q - q0) < batch ? (Q - q0) : batch;
+        rc = stage_scan(ctx, dq + q0 * 4, n, subsample, input_sorted, stream);
+        if (rc) return rc;
+        rc = stage_svd(ctx, 0, n, debug, offset_out(out, q0), stream,
+                       [&](int64_t c0, int64_t cn) { return after_chunk(q0 + c0, cn); });
+        if (rc) return rc;
     }
-    tq_ctx::Ev ev{};
-    if (ctx->timing) {
-        ctx->timed_calls++;
-        if (ctx->events_used == ctx->events.size()) {
-            tq_ctx::Ev e{};
-            TQ_HIP(ctx, hipEventCreate(&e.e0));
-            TQ_HIP(ctx, hipEventCreate(&e.e1));
-            TQ_HIP(ctx, hipEventCreate(&e.e2));
-            ctx->events.push_back(e);
-        }
-        ev = ctx->events[ctx->events_used++];
-        TQ_HIP(ctx, hipEventRecord(ev.e0, stream));
-        TQ_HIP(ctx, hipEventRecord(ev.e1, stream));       // stages overlap: only the total is meaningful
-    }
-    TQ_HIP(ctx, hipEventRecord(ctx->evIn, stream));
-    TQ_HIP(ctx, hipStreamWaitEvent(ctx->sA, ctx->evIn, 0));
-    TQ_HIP(ctx, hipStreamWaitEvent(ctx->sB, ctx->evIn, 0));
-    uint32_t *cm0 = ctx->d_cm;
-    int64_t i = 0;
-    for (int64_t q0 = 0; q0 < Q; q0 += sub, ++i) {
-        const int64_t n = (Q - q0) < sub ? (Q - q0) : sub;
-        const int b = (int)(i & 1);
-        // stream A: ordering + scan into slab b (after the SVD stage that last read slab b)
-        if (i >= 2) TQ_HIP(ctx, hipStreamWaitEvent(ctx->sA, ctx->evB[b], 0));
-        ctx->d_cm = cm0 + (size_t)b * (size_t)ctx->cm_quartets * 256;
-        const uint32_t *order = nullptr;
-        rc = make_order(ctx, dq + q0 * 4, n, ctx->sA, &order);
-        if (!rc) {
-            ctx->wpc_override = ctx->ov_scan_wgs * (ctx->scan_wg > 1 ? ctx->scan_wg : 8);
-            rc = launch_scan_n(ctx, dq + q0 * 4, order, n, subsample, ctx->sA);
-        }
-        if (!rc && hipEventRecord(ctx->evA[b], ctx->sA) != hipSuccess) rc = TQ_ERR_HIP;
-        // stream B: singular values of slab b
-        if (!rc && hipStreamWaitEvent(ctx->sB, ctx->evA[b], 0) != hipSuccess) rc = TQ_ERR_HIP;
-        if (!rc) {
-            ctx->wpc_override = ctx->ov_svd_waves;
-            const OutPtrs o = offset_out(out, q0);
-            rc = ctx->svd_method == 0 ? launch_svd<false>(ctx, dq + q0 * 4, n, o, ctx->sB)
-                                      : launch_hqr<false>(ctx, dq + q0 * 4, n, o, ctx->sB);
-        }
-        if (!rc && hipEventRecord(ctx->evB[b], ctx->sB) != hipSuccess) rc = TQ_ERR_HIP;
-        if (rc) break;
-    }
-    ctx->wpc_override = 0;
-    ctx->d_cm = cm0;
-    if (rc) return rc > 0 ? TQ_ERR_HIP : rc;
-    TQ_HIP(ctx, hipEventRecord(ctx->evEndA, ctx->sA));
-    TQ_HIP(ctx, hipEventRecord(ctx->evEndB, ctx->sB));
-    TQ_HIP(ctx, hipStreamWaitEvent(stream, ctx->evEndA, 0));
-    TQ_HIP(ctx, hipStreamWaitEvent(stream, ctx->evEndB, 0));
-    if (ctx->timing) TQ_HIP(ctx, hipEventRecord(ev.e2, stream));
+    ctx->scanned_Q = 0;          // the slab belongs to this call only
     return TQ_OK;
 }
 
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+int ensure_streams(tq_ctx *ctx)
+{
+    if (ctx->sK) return TQ_OK;
+    TQ_HIP(ctx, hipStreamCreateWithFlags(&ctx->sK, hipStreamNonBlocking));
+    TQ_HIP(ctx, hipStreamCreateWithFlags(&ctx->sC, hipStreamNonBlocking));
+    return TQ_OK;
+}
+
+int pipe_event(tq_ctx *ctx, size_t i, hipEvent_t *ev)
+{
+    try {
+        while (ctx->pipe_events.size() <= i) {
+            hipEvent_t e;
+            TQ_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            ctx->pipe_events.push_back(e);
+        }
+    } catch (...) {
+        return fail(ctx, TQ_ERR_OOM, "out of host memory");
+    }
+    *ev = ctx->pipe_events[i];
+    return TQ_OK;
+}
+
+// Results of the host-buffer API: kernels on stream sK, result copies on stream sC.  The copy of chunk i
+// (8 + 24 + 1 bytes per quartet) runs under the kernels of chunk i+1.  Destinations in page-locked
+// memory (tq_host_alloc, hipHostMalloc, hipHostRegister) are written by the copy engine directly;
+// pageable destinations go through two pinned staging pieces and one host memcpy per chunk, which the
+// host does while the GPU works on the next chunk.
+struct HostSink {
+    tq_ctx *ctx;
+    uint32_t *rstat;
+    double *rscor;
+    uint8_t *flags;
+    const OutPtrs *dev;            // device outputs of row 0
+    bool direct = false;
+    bool single = false;           // pageable destinations, one piece: ONE D2H of the contiguous device region
+    size_t off_rscor = 0, off_flags = 0;           // byte offsets of rscor / flags inside a staging piece
+    char *stage[2] = {nullptr, nullptr};
+    int64_t stage_rows = 0;
+    struct Pending { int64_t q0, n; hipEvent_t done; int buf; };
+    Pending pend[2];
+    int npend = 0;
+    size_t nchunk = 0;
+
+    int begin(int64_t Q)
+    {
+        direct = is_pinned(rstat, (size_t)Q * 8) && is_pinned(rscor, (size_t)Q * 24) &&
+                 (!flags || is_pinned(flags, (size_t)Q));
+        if (!direct) {
+            stage_rows = ctx->svd_chunk < Q ? ctx->svd_chunk : Q;
+            // small calls (the reference's distributor hands out chunks of a few thousand quartets,
+            // run_inference.py:73-96) are dominated by the number of HIP calls: when the whole call is one
+            // piece, the device outputs [rstat | rscor | flags] are one contiguous region -> one copy
+            single = Q <= ctx->svd_chunk && Q <= ctx->batch && dev->flags &&
+                     (const char *)dev->rscor > (const char *)dev->rstat && (const char *)dev->flags > (const char *)dev->rscor;
+            off_rscor = single ? (size_t)((const char *)dev->rscor - (const char *)dev->rstat) : (size_t)stage_rows * 8;
+            off_flags = single ? (size_t)((const char *)dev->flags - (const char *)dev->rstat) : (size_t)stage_rows * 32;
+            const size_t bytes = off_flags + (size_t)stage_rows;
+            for (int i = 0; i < (single ? 1 : 2); ++i)
+                if (pool().alloc(bytes, (void **)&stage[i]) != TQ_OK)
+                    return fail(ctx, TQ_ERR_OOM, "out of page-locked host memory for the result staging");
+        }
+        return TQ_OK;
+    }
+    int drain_one()
+    {
+        const Pending p = pend[0];
+        pend[0] = pend[1];
+        --npend;
+        TQ_HIP(ctx, hipEventSynchronize(p.done));
+        const char *s = stage[p.buf];
+        memcpy(rstat + p.q0 * 2, s, (size_t)p.n * 8);
+        memcpy(rscor + p.q0 * 3, s + off_rscor, (size_t)p.n * 24);
+        if (flags) memcpy(flags + p.q0, s + off_flags, (size_t)p.n);
+        return TQ_OK;
+    }
+    // chunk [q0, q0+n) has been enqueued on sK
+    int chunk(int64_t q0, int64_t n)
+    {
+        hipEvent_t ready, done;
+        int rc = pipe_event(ctx, 2 * (nchunk % 4), &ready);
+        if (!rc) rc = pipe_event(ctx, 2 * (nchunk % 4) + 1, &done);
+        if (rc) return rc;
+        TQ_HIP(ctx, hipEventRecord(ready, ctx->sK));
+        TQ_HIP(ctx, hipStreamWaitEvent(ctx->sC, ready, 0));
+        if (direct) {
+            TQ_HIP(ctx, hipMemcpyAsync(rstat + q0 * 2, dev->rstat + q0 * 2, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->sC));
+            TQ_HIP(ctx, hipMemcpyAsync(rscor + q0 * 3, dev->rscor + q0 * 3, (size_t)n * 24, hipMemcpyDeviceToHost, ctx->sC));
+            if (flags)
+                TQ_HIP(ctx, hipMemcpyAsync(flags + q0, dev->flags + q0, (size_t)n, hipMemcpyDeviceToHost, ctx->sC));
+        } else {
+            if (npend == 2) {                       // the staging piece this chunk needs is still in flight
+                rc = drain_one();
+                if (rc) return rc;
+            }
+            const int b = single ? 0 : (int)(nchunk & 1);
+            char *s = stage[b];
+            if (single) {
+                TQ_HIP(ctx, hipMemcpyAsync(s, dev->rstat, off_flags + (size_t)n, hipMemcpyDeviceToHost, ctx->sC));
+            } else {
+                TQ_HIP(ctx, hipMemcpyAsync(s, dev->rstat + q0 * 2, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->sC));
+                TQ_HIP(ctx, hipMemcpyAsync(s + off_rscor, dev->rscor + q0 * 3, (size_t)n * 24, hipMemcpyDeviceToHost,
+                                           ctx->sC));
+                if (flags)
+                    TQ_HIP(ctx, hipMemcpyAsync(s + off_flags, dev->flags + q0, (size_t)n, hipMemcpyDeviceToHost, ctx->sC));
+            }
+            TQ_HIP(ctx, hipEventRecord(done, ctx->sC));
+            pend[npend++] = Pending{q0, n, done, b};
+            if (npend == 2) {                       // copy out the older piece while the GPU works on
+                rc = drain_one();
+                if (rc) return rc;
+            }
+        }
+        ++nchunk;
+        return TQ_OK;
+    }
+    int finish()
+    {
+        int rc = TQ_OK;
+        while (npend && !rc) rc = drain_one();
+        if (!rc && hipStreamSynchronize(ctx->sC) != hipSuccess) rc = fail(ctx, TQ_ERR_HIP, "result copy failed");
+        return rc;
+    }
+    ~HostSink()
+    {
+        // never leave copies in flight into memory the caller may free
+        (void)hipStreamSynchronize(ctx->sK);
+        (void)hipStreamSynchronize(ctx->sC);
+        for (int i = 0; i < 2; ++i)
+            if (stage[i]) (void)pool().release(stage[i]);
+    }
+};
+
+// device quartets -> host results (synchronous)
+int resolve_to_host(tq_ctx *ctx, const uint32_t *dq, int64_t Q, int subsample, bool input_sorted, uint32_t *rstat,
+                    double *rscor, uint8_t *flags, uint32_t *d_rstat, double *d_rscor, uint8_t *d_flags)
+{
+    OutPtrs out{d_rstat, d_rscor, d_flags, nullptr, nullptr, nullptr};
+    HostSink sink{ctx, rstat, rscor, flags, &out};
+    int rc = sink.begin(Q);
+    if (rc) return rc;
+    rc = launch(ctx, dq, Q, subsample, false, input_sorted, out, ctx->sK,
+                [&](int64_t q0, int64_t n) { return sink.chunk(q0, n); });
+    if (rc) return rc;
+    return sink.finish();
+}
 
 }  // namespace
 
@@ -585,33 +805,34 @@ void tq_destroy(tq_ctx *ctx)
     free_data(ctx);
     free_source(ctx);
     if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
-    if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
     if (ctx->d_cm) (void)hipFree(ctx->d_cm);
     if (ctx->d_sort) (void)hipFree(ctx->d_sort);
     if (ctx->d_sort_tmp) (void)hipFree(ctx->d_sort_tmp);
     if (ctx->d_de) (void)hipFree(ctx->d_de);
     if (ctx->d_sv) (void)hipFree(ctx->d_sv);
     if (ctx->d_nsnps) (void)hipFree(ctx->d_nsnps);
-    if (ctx->sA) {
-        (void)hipStreamDestroy(ctx->sA);
-        (void)hipStreamDestroy(ctx->sB);
-        (void)hipEventDestroy(ctx->evIn);
-        (void)hipEventDestroy(ctx->evEndA);
-        (void)hipEventDestroy(ctx->evEndB);
-        for (int i = 0; i < 2; ++i) {
-            (void)hipEventDestroy(ctx->evA[i]);
-            (void)hipEventDestroy(ctx->evB[i]);
-        }
-    }
-    for (auto &e : ctx->events) {
-        (void)hipEventDestroy(e.e0);
-        (void)hipEventDestroy(e.e1);
-        (void)hipEventDestroy(e.e2);
-    }
+    if (ctx->sK) (void)hipStreamDestroy(ctx->sK);
+    if (ctx->sC) (void)hipStreamDestroy(ctx->sC);
+    for (auto e : ctx->pipe_events) (void)hipEventDestroy(e);
+    for (auto &m : ctx->marks) (void)hipEventDestroy(m.ev);
+    for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
     delete ctx;
 }
 
 const char *tq_last_error(const tq_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
+
+int tq_host_alloc(int64_t bytes, void **out)
+{
+    if (!out || bytes < 0) return TQ_ERR_INVALID_ARG;
+    *out = nullptr;
+    return pool().alloc((size_t)bytes, out);
+}
+
+int tq_host_free(void *p)
+{
+    if (!p) return TQ_OK;
+    return pool().release(p);
+}
 
 int tq_set_data(tq_ctx *ctx, const uint8_t *tmparr, int64_t T, int64_t S, const uint32_t *locus,
                 int64_t locus_stride)
@@ -625,18 +846,23 @@ int tq_set_data(tq_ctx *ctx, const uint8_t *tmparr, int64_t T, int64_t S, const 
     free_data(ctx);
 
     // contiguous copy of the locus column + the run-contiguity check subsample mode relies on
-    std::vector<uint32_t> loc((size_t)S);
+    std::vector<uint32_t> loc;
     bool ok = true, sorted = true;
-    for (int64_t i = 0; i < S; ++i) {
-        loc[(size_t)i] = locus[i * locus_stride];
-        if (loc[(size_t)i] == 0xFFFFFFFFu) ok = false;
-        if (i && loc[(size_t)i] < loc[(size_t)i - 1]) sorted = false;
-    }
-    if (ok && !sorted) {
-        std::unordered_set<uint32_t> seen;
-        seen.insert(loc[0]);
-        for (int64_t i = 1; i < S && ok; ++i)
-            if (loc[(size_t)i] != loc[(size_t)i - 1] && !seen.insert(loc[(size_t)i]).second) ok = false;
+    try {
+        loc.resize((size_t)S);
+        for (int64_t i = 0; i < S; ++i) {
+            loc[(size_t)i] = locus[i * locus_stride];
+            if (loc[(size_t)i] == 0xFFFFFFFFu) ok = false;
+            if (i && loc[(size_t)i] < loc[(size_t)i - 1]) sorted = false;
+        }
+        if (ok && !sorted) {
+            std::unordered_set<uint32_t> seen;
+            seen.insert(loc[0]);
+            for (int64_t i = 1; i < S && ok; ++i)
+                if (loc[(size_t)i] != loc[(size_t)i - 1] && !seen.insert(loc[(size_t)i]).second) ok = false;
+        }
+    } catch (const std::bad_alloc &) {
+        return fail(ctx, TQ_ERR_OOM, "tq_set_data: out of host memory");
     }
     ctx->locus_runs_ok = ok;
 
@@ -686,7 +912,33 @@ int tq_resolve_dev(tq_ctx *ctx, const uint32_t *d_quartets, int64_t Q, int subsa
         return fail(ctx, TQ_ERR_INVALID_ARG, "tq_resolve_dev: NULL pointer or negative Q");
     TQ_HIP(ctx, hipSetDevice(ctx->device));
     OutPtrs out{d_rstat, d_rscor, d_flags, nullptr, nullptr, nullptr};
-    return launch(ctx, d_quartets, Q, subsample, false, out, (hipStream_t)stream);
+    return launch(ctx, d_quartets, Q, subsample, false, false, out, (hipStream_t)stream, NoChunkHook());
+}
+
+int tq_scan_dev(tq_ctx *ctx, const uint32_t *d_quartets, int64_t Q, int subsample, void *stream)
+{
+    if (!ctx) return TQ_ERR_INVALID_ARG;
+    if (Q < 1 || !d_quartets) return fail(ctx, TQ_ERR_INVALID_ARG, "tq_scan_dev: NULL pointer or Q < 1");
+    if (Q > ctx->batch)
+        return fail(ctx, TQ_ERR_INVALID_ARG, "tq_scan_dev: Q=%lld exceeds the scan batch of %lld quartets (option 'batch')",
+                    (long long)Q, (long long)ctx->batch);
+    int rc = check_ready(ctx, subsample);
+    if (rc) return rc;
+    TQ_HIP(ctx, hipSetDevice(ctx->device));
+    if (ctx->timing) ctx->timed_calls++;
+    return stage_scan(ctx, d_quartets, Q, subsample, false, (hipStream_t)stream);
+}
+
+int tq_svd_dev(tq_ctx *ctx, int64_t q0, int64_t n, uint32_t *d_rstat, double *d_rscor, uint8_t *d_flags, void *stream)
+{
+    if (!ctx) return TQ_ERR_INVALID_ARG;
+    if (n < 0 || (n > 0 && (!d_rstat || !d_rscor)))
+        return fail(ctx, TQ_ERR_INVALID_ARG, "tq_svd_dev: NULL pointer or negative n");
+    if (ctx->scanned_Q == 0) return fail(ctx, TQ_ERR_NO_DATA, "tq_svd_dev: no scanned batch (call tq_scan_dev first)");
+    if (n == 0) return TQ_OK;
+    TQ_HIP(ctx, hipSetDevice(ctx->device));
+    OutPtrs out{d_rstat, d_rscor, d_flags, nullptr, nullptr, nullptr};
+    return stage_svd(ctx, q0, n, false, out, (hipStream_t)stream, NoChunkHook());
 }
 
 int tq_unrank_dev(tq_ctx *ctx, const uint64_t *d_ranks, int64_t Q, uint32_t *d_quartets, void *stream)
@@ -727,10 +979,28 @@ int tq_resolve_range_dev(tq_ctx *ctx, uint64_t first_rank, int64_t Q, int subsam
                        (const uint64_t *)nullptr, first_rank, Q, (int32_t)ctx->T, dq);
     TQ_HIP(ctx, hipGetLastError());
     OutPtrs out{d_rstat, d_rscor, d_flags, nullptr, nullptr, nullptr};
-    ctx->input_sorted = true;            // consecutive lexicographic ranks are in (a,b,c) order already
-    const int rc = launch(ctx, dq, Q, subsample, false, out, (hipStream_t)stream);
-    ctx->input_sorted = false;
-    return rc;
+    // consecutive lexicographic ranks are in (a,b,c) order already
+    return launch(ctx, dq, Q, subsample, false, true, out, (hipStream_t)stream, NoChunkHook());
+}
+
+int tq_resolve_to_host(tq_ctx *ctx, const uint32_t *d_quartets, int64_t Q, int subsample, uint32_t *rstat,
+                       double *rscor, uint8_t *flags)
+{
+    if (!ctx) return TQ_ERR_INVALID_ARG;
+    if (Q < 0 || (Q > 0 && (!d_quartets || !rstat || !rscor)))
+        return fail(ctx, TQ_ERR_INVALID_ARG, "tq_resolve_to_host: NULL pointer or negative Q");
+    int rc = check_ready(ctx, subsample);
+    if (rc) return rc;
+    if (Q == 0) return TQ_OK;
+    TQ_HIP(ctx, hipSetDevice(ctx->device));
+    if ((rc = ensure_streams(ctx))) return rc;
+    const size_t o_rstat = 0;
+    const size_t o_rscor = align_up(o_rstat + (size_t)Q * 8, 256);
+    const size_t o_flags = align_up(o_rscor + (size_t)Q * 24, 256);
+    if ((rc = ensure_scratch(ctx, align_up(o_flags + (size_t)Q, 256)))) return rc;
+    char *base = (char *)ctx->d_scratch;
+    return resolve_to_host(ctx, d_quartets, Q, subsample, false, rstat, rscor, flags, (uint32_t *)(base + o_rstat),
+                           (double *)(base + o_rscor), (uint8_t *)(base + o_flags));
 }
 
 int tq_resolve_debug(tq_ctx *ctx, const uint32_t *quartets, int64_t Q, int subsample, uint32_t *rstat,
@@ -739,7 +1009,8 @@ int tq_resolve_debug(tq_ctx *ctx, const uint32_t *quartets, int64_t Q, int subsa
     if (!ctx) return TQ_ERR_INVALID_ARG;
     if (Q < 0 || (Q > 0 && (!quartets || !rstat || !rscor)))
         return fail(ctx, TQ_ERR_INVALID_ARG, "tq_resolve: NULL pointer or negative Q");
-    if (!ctx->have_data) return fail(ctx, TQ_ERR_NO_DATA, "tq_set_data has not been called");
+    int rc = check_ready(ctx, subsample);
+    if (rc) return rc;
     if (Q == 0) return TQ_OK;
     TQ_HIP(ctx, hipSetDevice(ctx->device));
     // taxon indices are checked on the host here; the kernel re-checks and flags them
@@ -758,7 +1029,7 @@ int tq_resolve_debug(tq_ctx *ctx, const uint32_t *quartets, int64_t Q, int subsa
         sorted &= key >= prev_key;
         prev_key = key;
     }
-    ctx->input_sorted = sorted && ctx->T < (1 << 21);
+    const bool input_sorted = sorted && ctx->T < (1 << 21);
     const bool debug = cmats || svds || ranks;
     const size_t o_q = 0;
     const size_t o_rstat = align_up(o_q + (size_t)Q * 16, 256);
@@ -768,22 +1039,14 @@ int tq_resolve_debug(tq_ctx *ctx, const uint32_t *quartets, int64_t Q, int subsa
     const size_t o_sv = align_up(o_cm + (cmats ? (size_t)Q * 3072 : 0), 256);
     const size_t o_rk = align_up(o_sv + (svds ? (size_t)Q * 384 : 0), 256);
     const size_t total = align_up(o_rk + (ranks ? (size_t)Q * 12 : 0), 256);
-    int rc = ensure_scratch(ctx, total);
-    if (rc) return rc;
+    if ((rc = ensure_scratch(ctx, total))) return rc;
+    if ((rc = ensure_streams(ctx))) return rc;
     char *base = (char *)ctx->d_scratch;
-    // Small calls (the reference's distributor hands out chunks of a few thousand quartets,
-    // run_inference.py:73-96) are dominated by the number of blocking HIP calls: they go through one
-    // pinned staging buffer -- one H2D, one D2H for the three result arrays -- instead of four pageable
-    // copies.  Large calls keep the direct copies (an extra host pass over 49 B/quartet costs more).
-    const bool staged = !debug && o_cm <= STAGE_LIMIT;
-    if (staged) {
-        rc = ensure_stage(ctx, o_cm);
-        if (rc) return rc;
-        memcpy(ctx->h_stage, quartets, (size_t)Q * 16);
-        TQ_HIP(ctx, hipMemcpyAsync(base + o_q, ctx->h_stage, (size_t)Q * 16, hipMemcpyHostToDevice, nullptr));
-    } else {
-        TQ_HIP(ctx, hipMemcpy(base + o_q, quartets, (size_t)Q * 16, hipMemcpyHostToDevice));
-    }
+    // quartets H2D on the compute stream (asynchronous when the caller's array is page-locked)
+    TQ_HIP(ctx, hipMemcpyAsync(base + o_q, quartets, (size_t)Q * 16, hipMemcpyHostToDevice, ctx->sK));
+    if (!debug)
+        return resolve_to_host(ctx, (const uint32_t *)(base + o_q), Q, subsample, input_sorted, rstat, rscor, flags,
+                               (uint32_t *)(base + o_rstat), (double *)(base + o_rscor), (uint8_t *)(base + o_flags));
     OutPtrs out;
     out.rstat = (uint32_t *)(base + o_rstat);
     out.rscor = (double *)(base + o_rscor);
@@ -791,19 +1054,12 @@ int tq_resolve_debug(tq_ctx *ctx, const uint32_t *quartets, int64_t Q, int subsa
     out.cmats = cmats ? (uint32_t *)(base + o_cm) : nullptr;
     out.svds = svds ? (double *)(base + o_sv) : nullptr;
     out.ranks = ranks ? (int32_t *)(base + o_rk) : nullptr;
-    rc = launch(ctx, (const uint32_t *)(base + o_q), Q, subsample, debug, out, nullptr);
-    ctx->input_sorted = false;
-    if (rc) return rc;
-    if (staged) {
-        TQ_HIP(ctx, hipMemcpyAsync((char *)ctx->h_stage + o_rstat, base + o_rstat, o_cm - o_rstat, hipMemcpyDeviceToHost,
-                                   nullptr));
-        TQ_HIP(ctx, hipStreamSynchronize(nullptr));
-        memcpy(rstat, (char *)ctx->h_stage + o_rstat, (size_t)Q * 8);
-        memcpy(rscor, (char *)ctx->h_stage + o_rscor, (size_t)Q * 24);
-        if (flags) memcpy(flags, (char *)ctx->h_stage + o_flags, (size_t)Q);
-        return TQ_OK;
+    rc = launch(ctx, (const uint32_t *)(base + o_q), Q, subsample, true, input_sorted, out, ctx->sK, NoChunkHook());
+    if (rc) {
+        (void)hipStreamSynchronize(ctx->sK);
+        return rc;
     }
-    TQ_HIP(ctx, hipDeviceSynchronize());
+    TQ_HIP(ctx, hipStreamSynchronize(ctx->sK));
     TQ_HIP(ctx, hipMemcpy(rstat, out.rstat, (size_t)Q * 8, hipMemcpyDeviceToHost));
     TQ_HIP(ctx, hipMemcpy(rscor, out.rscor, (size_t)Q * 24, hipMemcpyDeviceToHost));
     if (flags) TQ_HIP(ctx, hipMemcpy(flags, out.flags, (size_t)Q, hipMemcpyDeviceToHost));
@@ -826,30 +1082,43 @@ int tq_timing_enable(tq_ctx *ctx, int on)
     return TQ_OK;
 }
 
-int tq_timing_read(tq_ctx *ctx, double *kernel_ms, int64_t *launches)
+int tq_timing_read_kernels(tq_ctx *ctx, double *ms, int n_ms, int64_t *calls)
 {
-    return tq_timing_read_split(ctx, kernel_ms, nullptr, nullptr, launches);
+    if (!ctx || (n_ms > 0 && !ms)) return TQ_ERR_INVALID_ARG;
+    double t[TAG_COUNT] = {0, 0, 0, 0, 0};
+    hipEvent_t prev = nullptr;
+    int rc = TQ_OK;
+    for (auto &m : ctx->marks) {
+        if (!rc && hipEventSynchronize(m.ev) != hipSuccess) rc = fail(ctx, TQ_ERR_HIP, "timing event failed");
+        if (!rc && m.tag >= 0 && m.tag < TAG_COUNT && prev) {
+            float a = 0.f;
+            if (hipEventElapsedTime(&a, prev, m.ev) == hipSuccess) t[m.tag] += a;
+        }
+        prev = m.ev;
+        ctx->event_pool.push_back(m.ev);
+    }
+    ctx->marks.clear();
+    for (int i = 0; i < n_ms; ++i) ms[i] = i < TAG_COUNT ? t[i] : 0.0;
+    if (calls) *calls = ctx->timed_calls;
+    ctx->timed_calls = 0;
+    return rc;
 }
 
 int tq_timing_read_split(tq_ctx *ctx, double *total_ms, double *scan_ms, double *svd_ms, int64_t *calls)
 {
-    if (!ctx) return TQ_ERR_INVALID_ARG;
-    double t_scan = 0.0, t_svd = 0.0;
-    for (size_t i = 0; i < ctx->events_used; ++i) {
-        TQ_HIP(ctx, hipEventSynchronize(ctx->events[i].e2));
-        float a = 0.f, b = 0.f;
-        TQ_HIP(ctx, hipEventElapsedTime(&a, ctx->events[i].e0, ctx->events[i].e1));
-        TQ_HIP(ctx, hipEventElapsedTime(&b, ctx->events[i].e1, ctx->events[i].e2));
-        t_scan += a;
-        t_svd += b;
-    }
-    if (total_ms) *total_ms = t_scan + t_svd;
-    if (scan_ms) *scan_ms = t_scan;
-    if (svd_ms) *svd_ms = t_svd;
-    if (calls) *calls = ctx->timed_calls;
-    ctx->events_used = 0;
-    ctx->timed_calls = 0;
+    double t[TAG_COUNT];
+    const int rc = tq_timing_read_kernels(ctx, t, TAG_COUNT, calls);
+    if (rc) return rc;
+    const double a = t[TAG_ORDER] + t[TAG_SCAN], b = t[TAG_BIDIAG] + t[TAG_BDSQR] + t[TAG_SCORE];
+    if (total_ms) *total_ms = a + b;
+    if (scan_ms) *scan_ms = a;
+    if (svd_ms) *svd_ms = b;
     return TQ_OK;
+}
+
+int tq_timing_read(tq_ctx *ctx, double *kernel_ms, int64_t *launches)
+{
+    return tq_timing_read_split(ctx, kernel_ms, nullptr, nullptr, launches);
 }
 
 int tq_set_option(tq_ctx *ctx, const char *name, int64_t value)
@@ -866,11 +1135,6 @@ int tq_set_option(tq_ctx *ctx, const char *name, int64_t value)
         ctx->waves_per_cu = (int)value;
         return TQ_OK;
     }
-    if (!strcmp(name, "overlap")) {
-        if (value < 0) return fail(ctx, TQ_ERR_INVALID_ARG, "overlap must be >= 0");
-        ctx->overlap = value;
-        return TQ_OK;
-    }
     if (!strcmp(name, "xcd_remap")) {
         ctx->xcd_remap = value != 0;
         return TQ_OK;
@@ -880,14 +1144,14 @@ int tq_set_option(tq_ctx *ctx, const char *name, int64_t value)
         ctx->svd_wpc = (int)value;
         return TQ_OK;
     }
-    if (!strcmp(name, "ov_scan_wgs")) {
-        if (value < 0 || value > 8) return fail(ctx, TQ_ERR_INVALID_ARG, "ov_scan_wgs must be 0..8 (0: one block per workgroup)");
-        ctx->ov_scan_wgs = (int)value;
+    if (!strcmp(name, "svd_chunk")) {
+        if (value < 0) return fail(ctx, TQ_ERR_INVALID_ARG, "svd_chunk must be >= 0");
+        ctx->svd_chunk = value ? value : (1 << 17);
         return TQ_OK;
     }
-    if (!strcmp(name, "ov_svd_waves")) {
-        if (value < 1 || value > 32) return fail(ctx, TQ_ERR_INVALID_ARG, "ov_svd_waves must be 1..32");
-        ctx->ov_svd_waves = (int)value;
+    if (!strcmp(name, "bdsqr_maxit")) {
+        if (value < 0 || value > 1000) return fail(ctx, TQ_ERR_INVALID_ARG, "bdsqr_maxit must be 0..1000");
+        ctx->bdsqr_maxit = value ? (int)value : 60;
         return TQ_OK;
     }
     if (!strcmp(name, "scan_wg")) {
@@ -908,7 +1172,7 @@ int tq_set_option(tq_ctx *ctx, const char *name, int64_t value)
     }
     if (!strcmp(name, "scan_method")) {
         if (value != 0 && value != 1 && value != -1 && value != 2 && value != 3)
-            return fail(ctx, TQ_ERR_INVALID_ARG, "scan_method must be -1 (auto), 0, 1 (or 2: timing diagnostic)");
+            return fail(ctx, TQ_ERR_INVALID_ARG, "scan_method must be -1 (auto), 0, 1 (or 2, 3: timing diagnostics)");
         ctx->scan_method = (int)value;
         return TQ_OK;
     }

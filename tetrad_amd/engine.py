@@ -20,6 +20,40 @@ def _ptr(a):
     return ctypes.c_void_p(a.ctypes.data) if a is not None else None
 
 
+class _PinnedBlock:
+    """One block of the library's page-locked host pool (tq_host_alloc); returned to the pool when the
+    last NumPy view of it is garbage-collected."""
+    __slots__ = ("ptr", "nbytes", "_free", "__weakref__")
+
+    def __init__(self, nbytes: int):
+        lib = _lib.load()
+        p = ctypes.c_void_p()
+        rc = lib.tq_host_alloc(int(nbytes), ctypes.byref(p))
+        if rc != 0 or not p.value:
+            raise TetradHipError(rc or -6, f"tq_host_alloc({nbytes}) failed")
+        self.ptr, self.nbytes, self._free = p.value, int(nbytes), lib.tq_host_free
+
+    @property
+    def __array_interface__(self):
+        return {"shape": (self.nbytes,), "typestr": "|u1", "data": (self.ptr, False), "version": 3}
+
+    def __del__(self):
+        try:
+            self._free(ctypes.c_void_p(self.ptr))
+        except Exception:  # interpreter shutdown
+            pass
+
+
+def pinned_empty(shape, dtype) -> np.ndarray:
+    """An uninitialised NumPy array in page-locked host memory from the library's pool: the copy engine
+    reads / writes it directly, asynchronously under the kernels (no staging, no extra host pass)."""
+    dtype = np.dtype(dtype)
+    shape = (shape,) if np.isscalar(shape) else tuple(shape)
+    n = int(np.prod(shape, dtype=np.int64)) * dtype.itemsize
+    raw = np.asarray(_PinnedBlock(max(n, 1)))           # .base keeps the block alive
+    return raw[:n].view(dtype).reshape(shape)
+
+
 class QuartetEngine:
     def __init__(self, device_id: int = 0):
         self._lib = _lib.load()
@@ -30,6 +64,9 @@ class QuartetEngine:
         self._h = h
         self.device_id = int(device_id)
         self.T = self.S = 0
+        #: bumped whenever the resident replicate is replaced (set_data / bootstrap); lets the API
+        #: mirrors notice that what they uploaded is no longer what the device holds
+        self.data_generation = 0
 
     # -- lifecycle ---------------------------------------------------------
     def close(self):
@@ -69,6 +106,7 @@ class QuartetEngine:
         if tm.shape[0] != tmparr.shape[1]:
             raise ValueError("tmpmap rows must equal tmparr columns")
         T, S = tmparr.shape
+        self.data_generation += 1
         self._check(self._lib.tq_set_data(self._h, _ptr(tmparr), T, S, _ptr(tm), stride))
         self.T, self.S = T, S
 
@@ -85,6 +123,7 @@ class QuartetEngine:
         """Build the replicate for resampled loci `lidxs` on the device; returns its number of sites."""
         lidxs = np.ascontiguousarray(lidxs, dtype=np.int64)
         S = ctypes.c_int64()
+        self.data_generation += 1
         self._check(self._lib.tq_bootstrap(self._h, _ptr(lidxs), lidxs.shape[0], int(seed_shuffle), int(seed_ambig),
                                            ctypes.byref(S)))
         T = ctypes.c_int64()
@@ -108,12 +147,19 @@ class QuartetEngine:
     # -- host-buffer API -----------------------------------------------------
     def resolve(self, quartets: np.ndarray, subsample_snps: bool = True, debug: bool = False):
         """Returns (rstat u32[Q,2], rscor f64[Q,3], flags u8[Q]) and, with ``debug``,
-        a dict with cmats u32[Q,3,16,16], svds f64[Q,3,16], ranks i32[Q,3]."""
-        q = np.ascontiguousarray(quartets, dtype=np.uint32).reshape(-1, 4)
+        a dict with cmats u32[Q,3,16,16], svds f64[Q,3,16], ranks i32[Q,3].
+        The result arrays live in page-locked memory of the library's pool (ordinary NumPy arrays to the
+        caller), so the result D2H runs under the kernels."""
+        q = quartets
+        if not (isinstance(q, np.ndarray) and q.dtype == np.uint32 and q.flags.c_contiguous):
+            src = np.asarray(quartets)
+            q = pinned_empty((src.size // 4, 4), np.uint32)      # the conversion copy lands in pinned memory
+            q[...] = src.reshape(-1, 4)
+        q = q.reshape(-1, 4)
         Q = q.shape[0]
-        rstat = np.zeros((Q, 2), np.uint32)
-        rscor = np.zeros((Q, 3), np.float64)
-        flags = np.zeros(Q, np.uint8)
+        rstat = pinned_empty((Q, 2), np.uint32)
+        rscor = pinned_empty((Q, 3), np.float64)
+        flags = pinned_empty(Q, np.uint8)
         if debug:
             cm = np.zeros((Q, 3, 16, 16), np.uint32)
             sv = np.zeros((Q, 3, 16), np.float64)
@@ -124,6 +170,17 @@ class QuartetEngine:
             return rstat, rscor, flags, dict(cmats=cm, svds=sv, ranks=rk)
         self._check(self._lib.tq_resolve(
             self._h, _ptr(q), Q, int(bool(subsample_snps)), _ptr(rstat), _ptr(rscor), _ptr(flags)))
+        return rstat, rscor, flags
+
+    def resolve_to_host(self, d_quartets: int, Q: int, subsample_snps: bool = True, out=None):
+        """Quartets on the device (address), results to host arrays: (rstat, rscor, flags).  ``out`` may
+        hold the three arrays to fill (any NumPy arrays of the right shape; pinned ones are written by the
+        copy engine directly)."""
+        if out is None:
+            out = (pinned_empty((Q, 2), np.uint32), pinned_empty((Q, 3), np.float64), pinned_empty(Q, np.uint8))
+        rstat, rscor, flags = out
+        self._check(self._lib.tq_resolve_to_host(
+            self._h, d_quartets, Q, int(bool(subsample_snps)), _ptr(rstat), _ptr(rscor), _ptr(flags)))
         return rstat, rscor, flags
 
     # -- device-pointer API (addresses as ints, e.g. torch.Tensor.data_ptr()) -------
@@ -138,6 +195,14 @@ class QuartetEngine:
         self._check(self._lib.tq_resolve_range_dev(
             self._h, first_rank, Q, int(bool(subsample_snps)), d_quartets or None, d_rstat,
             d_rscor, d_flags or None, stream or None))
+
+    def scan_dev(self, d_quartets: int, Q: int, subsample_snps: bool, stream: int = 0):
+        """Stage 1 (ordering + site scan) of quartets [0,Q) into the context's count slab."""
+        self._check(self._lib.tq_scan_dev(self._h, d_quartets, Q, int(bool(subsample_snps)), stream or None))
+
+    def svd_dev(self, q0: int, n: int, d_rstat: int, d_rscor: int, d_flags: int = 0, stream: int = 0):
+        """Stage 2 for rows [q0, q0+n) of the scanned batch; the pointers are the outputs OF ROW q0."""
+        self._check(self._lib.tq_svd_dev(self._h, q0, n, d_rstat, d_rscor, d_flags or None, stream or None))
 
     def unrank_dev(self, d_ranks: int, Q: int, d_quartets: int, stream: int = 0):
         self._check(self._lib.tq_unrank_dev(self._h, d_ranks, Q, d_quartets, stream or None))
@@ -159,6 +224,15 @@ class QuartetEngine:
         self._check(self._lib.tq_timing_read_split(
             self._h, ctypes.byref(tot), ctypes.byref(a), ctypes.byref(b), ctypes.byref(n)))
         return tot.value, a.value, b.value, n.value
+
+    KERNEL_TAGS = ("order", "scan", "bidiag", "bdsqr", "score")
+
+    def timing_read_kernels(self):
+        """({"order","scan","bidiag","bdsqr","score"} -> summed ms, resolve_calls) since the last read."""
+        ms = (ctypes.c_double * 5)()
+        n = ctypes.c_int64()
+        self._check(self._lib.tq_timing_read_kernels(self._h, ms, 5, ctypes.byref(n)))
+        return dict(zip(self.KERNEL_TAGS, list(ms))), n.value
 
     def debug_fetch(self, which: str, n: int) -> np.ndarray:
         """Scratch of the last resolve call (test hook): 'cm' u32[n,256], 'de' f64[3n,32], 'sv' f64[3n,16]."""

@@ -1,56 +1,20 @@
-"""wQMC input lines from the quartets TSV -- host-side mirror of
-tetrad/src/run_inference.py:254-327 (the consumer right after the hot path).
+"""wQMC input lines for the consumer right after the hot path.
 
-Same arithmetic on the same text: the reference re-reads the `%.6f`-rounded scores from the TSV,
-so this mirror does too (weights computed from full-precision scores would differ in the 6th
-decimal).  The reference shuffles the file with an unseeded `shuf` (:326-327); here the shuffle is
-in-process and seedable.
+The reference writes the quartets TSV, re-reads it line by line and formats "a,b|c,d:weight"
+(tetrad/src/run_inference.py:254-327).  Here the lines are produced by the native formatter of the
+C ABI (`tq_format_qmc`: weights 0-3, `min_snps`, `min_ratio`; the scores are rounded to six decimals
+first, exactly as the reference reads them back from the file) -- straight from the result arrays,
+or from a TSV parsed back into arrays.  The reference shuffles the file with an unseeded `shuf`
+(:326-327); here the shuffle is in-process and seedable.
+
+The line-by-line restatement of the reference's formatter that this module is tested against lives
+in oracle/qmc_format.py (test infrastructure).
 """
 from __future__ import annotations
 
-from itertools import islice
 from pathlib import Path
 
 import numpy as np
-
-
-def iter_qmc_formatted(qrts_file: Path, weights: int, min_snps: int = 0, min_ratio: float = 1.0):
-    """run_inference.py:254-305.  Yields "a,b|c,d:weight" strings."""
-    min_snps = max(1, min_snps)                                   # :258
-    with open(qrts_file, "r") as datain:
-        for line in datain:
-            values = line.split("\t")
-            order = int(values[7])                                # :264-270: topology -> split
-            if order == 1:
-                qrts = values[0], values[2], values[1], values[3]
-            elif order == 2:
-                qrts = values[0], values[3], values[1], values[2]
-            else:
-                qrts = values[:4]
-            scores = np.array(values[4:7], dtype=np.float64)
-            nsnps = int(values[8])
-            if nsnps < min_snps:                                  # :275
-                continue
-            if not weights:                                       # :280-297
-                weight = 1.0
-                ratio = 1.0
-            else:
-                scores = np.array(sorted(scores))
-                smean = scores[1:].mean()
-                smin = scores.min()
-                ratio = 1. if not smin else smean / smin
-                if weights == 1:
-                    weight = smean
-                elif weights == 2:
-                    weight = ratio
-                elif weights == 3:
-                    weight = 1. - smin / scores.sum()
-                else:
-                    raise ValueError(f"no weight strategy {weights}")
-            if ratio < min_ratio:                                 # :300
-                continue
-            yield "{},{}|{},{}:{:.5f}".format(*qrts, weight)     # :305
-
 
 def qmc_lines(rqrts: np.ndarray, rscor: np.ndarray, rstat: np.ndarray, weights: int = 0, min_snps: int = 0,
               min_ratio: float = 1.0) -> list[bytes]:
@@ -90,15 +54,32 @@ def write_qmc_from_arrays(rqrts, rscor, rstat, qmc_in_file: Path, weights: int =
     return len(lines)
 
 
+def read_quartets_tsv(qrts_file: Path):
+    """The 9-column quartets TSV (run_inference.py:233-234) back into `(rqrts u32[n,4], rscor f64[n,3],
+    rstat u32[n,2])`."""
+    import pandas as pd
+    cols = list(range(9))
+    dtypes = {0: np.uint32, 1: np.uint32, 2: np.uint32, 3: np.uint32, 4: np.float64, 5: np.float64, 6: np.float64,
+              7: np.uint32, 8: np.uint32}
+    try:
+        tab = pd.read_csv(qrts_file, sep="\t", header=None, names=cols, dtype=dtypes)
+    except pd.errors.EmptyDataError:
+        tab = pd.DataFrame({c: np.zeros(0, dtypes[c]) for c in cols})
+    rqrts = np.ascontiguousarray(tab[[0, 1, 2, 3]].to_numpy(np.uint32))
+    rscor = np.ascontiguousarray(tab[[4, 5, 6]].to_numpy(np.float64))
+    rstat = np.ascontiguousarray(tab[[7, 8]].to_numpy(np.uint32))
+    return rqrts, rscor, rstat
+
+
+def iter_qmc_formatted(qrts_file: Path, weights: int, min_snps: int = 0, min_ratio: float = 1.0):
+    """Same lines, same order as run_inference.py:254-305 yields for `qrts_file` (native formatter)."""
+    rqrts, rscor, rstat = read_quartets_tsv(qrts_file)
+    for line in qmc_lines(rqrts, rscor, rstat, weights, min_snps, min_ratio):
+        yield line.decode("ascii")
+
+
 def write_qmc_format(qrts_file: Path, qmc_in_file: Path, weights: int = 0, min_snps: int = 0,
-                     min_ratio: float = 1.0, seed=None) -> None:
-    """run_inference.py:308-327: formatted lines in random order (seedable instead of `shuf`)."""
-    lines = list(iter_qmc_formatted(qrts_file, weights, min_snps, min_ratio))
-    np.random.default_rng(seed).shuffle(lines)
-    with open(qmc_in_file, "w") as out:
-        it = iter(lines)
-        while True:
-            chunk = "\n".join(islice(it, 50_000))                 # :311
-            if not chunk:
-                break
-            out.write(chunk + "\n")
+                     min_ratio: float = 1.0, seed=None) -> int:
+    """run_inference.py:308-327 for a TSV on disk; returns the number of lines written."""
+    rqrts, rscor, rstat = read_quartets_tsv(qrts_file)
+    return write_qmc_from_arrays(rqrts, rscor, rstat, qmc_in_file, weights, min_snps, min_ratio, seed)

@@ -17,6 +17,7 @@ from pathlib import Path
 
 import numpy as np
 
+from ._lib import FLAG_NO_CONVERGENCE
 from .engine import QuartetEngine
 
 _engines: dict[int, QuartetEngine] = {}
@@ -31,17 +32,41 @@ def get_engine(device_id: int = 0) -> QuartetEngine:
     return eng
 
 
-def _ensure_resident(eng: QuartetEngine, tmparr: np.ndarray, tmpmap: np.ndarray):
-    """Upload once per replicate, not once per chunk: skip the H2D when the same
-    arrays (identity + shape) are already on the device."""
-    key = (id(tmparr), id(tmpmap), tmparr.shape, tmpmap.shape)
-    if _resident.get(eng.device_id, (None,))[0] != key:
+def _fingerprint(a: np.ndarray) -> tuple:
+    """Content fingerprint of an array (xxh3-64 over the bytes; ~0.1 ms per MB)."""
+    a = np.ascontiguousarray(a)
+    try:
+        import xxhash
+        h = xxhash.xxh3_64_intdigest(memoryview(a).cast("B"))
+    except ImportError:  # pragma: no cover
+        import zlib
+        h = zlib.crc32(memoryview(a).cast("B"))
+    return (a.shape, a.dtype.str, h)
+
+
+def _ensure_resident(eng: QuartetEngine, tmparr: np.ndarray, tmpmap: np.ndarray, replicate_token=None):
+    """Upload once per replicate, not once per chunk.  The H2D is skipped only when the device still
+    holds what this function uploaded last (the engine's data generation is unchanged: nobody called
+    `set_data` / `bootstrap` on it in between) AND the arrays are the same replicate: equal
+    `replicate_token` when the caller passes one (any hashable; e.g. the bootstrap index), otherwise
+    equal content fingerprints -- so an array refilled in place between replicates is uploaded again,
+    as the reference re-reads its database on every call (resolve_quartets.py:33-35)."""
+    key = ("token", replicate_token, tmparr.shape, tmpmap.shape) if replicate_token is not None \
+        else ("content", _fingerprint(tmparr), _fingerprint(tmpmap))
+    if _resident.get(eng.device_id) != (key, eng.data_generation):
         eng.set_data(tmparr, tmpmap)
-        # keep the arrays alive so the ids stay unique while resident
-        _resident[eng.device_id] = (key, tmparr, tmpmap)
+        _resident[eng.device_id] = (key, eng.data_generation)
 
 
-def new_infer_resolved_quartets(tmparr, tmpmap, quartets, subsample_snps, device_id: int = 0):
+def invalidate(device_id: int | None = None):
+    """Forget what is resident (all devices when `device_id` is None): the next call uploads again."""
+    if device_id is None:
+        _resident.clear()
+    else:
+        _resident.pop(device_id, None)
+
+
+def new_infer_resolved_quartets(tmparr, tmpmap, quartets, subsample_snps, device_id: int = 0, replicate_token=None):
     """resolve_quartets.py:191-265 -> (quartets u32[Q,4], rstat u32[Q,2], rscor f64[Q,3]).
 
     Zero-data quartets (no countable site): the reference stores an unseeded
@@ -50,9 +75,11 @@ def new_infer_resolved_quartets(tmparr, tmpmap, quartets, subsample_snps, device
     eng = get_engine(device_id)
     tmparr = np.asarray(tmparr)
     tmpmap = np.asarray(tmpmap)
-    _ensure_resident(eng, tmparr, tmpmap)
+    _ensure_resident(eng, tmparr, tmpmap, replicate_token)
     quartets = np.ascontiguousarray(quartets, dtype=np.uint32).reshape(-1, 4)
-    rstat, rscor, _ = eng.resolve(quartets, subsample_snps)
+    rstat, rscor, flags = eng.resolve(quartets, subsample_snps)
+    if (flags & FLAG_NO_CONVERGENCE).any():                       # np.linalg.svd raises the same (:242)
+        raise np.linalg.LinAlgError("SVD did not converge")
     return quartets, rstat, rscor
 
 
@@ -60,19 +87,21 @@ def infer_resolved_quartets(database: Path, nsamples: int, qrts, subsample_snps:
                             device_id: int = 0):
     """resolve_quartets.py:17-39.  ``database`` is the project's HDF5 file with
     datasets ``tmparr`` and ``tmpmap`` (h5py), or an ``.npz`` with the same two arrays."""
-    qrts = np.array(list(qrts), dtype=np.uint32)              # :28
-    tmparr, tmpmap = load_database(database)                  # :33-35
-    return new_infer_resolved_quartets(tmparr, tmpmap, qrts, subsample_snps, device_id)
+    qrts = np.array(list(qrts), dtype=np.uint32).reshape(-1, 4)   # :28
+    tmparr, tmpmap, token = load_database(database, with_token=True)   # :33-35
+    return new_infer_resolved_quartets(tmparr, tmpmap, qrts, subsample_snps, device_id, replicate_token=token)
 
 
 _db_cache: dict = {}
 
 
-def load_database(database):
-    """Read tmparr/tmpmap; cached on (path, mtime) so chunk calls of one replicate
-    reuse the arrays (and therefore the device-resident copy)."""
+def load_database(database, with_token: bool = False):
+    """Read tmparr/tmpmap; cached on (path, mtime, size) so chunk calls of one replicate reuse the
+    arrays (and therefore the device-resident copy).  The cached arrays are private to this module, so
+    the cache key doubles as the replicate token of `_ensure_resident`."""
     path = Path(database)
-    key = (str(path), path.stat().st_mtime_ns)
+    st = path.stat()
+    key = (str(path.resolve()), st.st_mtime_ns, st.st_size)
     hit = _db_cache.get("key") == key
     if not hit:
         if path.suffix == ".npz":
@@ -84,6 +113,8 @@ def load_database(database):
                 tmparr = io5["tmparr"][:]
                 tmpmap = io5["tmpmap"][:]
         _db_cache.update(key=key, tmparr=tmparr, tmpmap=tmpmap)
+    if with_token:
+        return _db_cache["tmparr"], _db_cache["tmpmap"], key
     return _db_cache["tmparr"], _db_cache["tmpmap"]
 
 

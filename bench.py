@@ -1,30 +1,36 @@
 #!/usr/bin/env python
 """bench.py -- resolved quartets/s of the per-quartet hot path on N MI355X.
 
-One "step" = one pass of the hot path (tq_resolve_dev: site scan -> 16x16 count matrices ->
-3 singular-value decompositions -> scores/topology) over one batch of synthetic quartets that
-is already resident in HBM, plus -- for N > 1 -- the RCCL all-gather of the result records.
+One "step" = one pass of the hot path over one batch of synthetic quartets: ordering + site scan
+-> 16x16 count matrices -> 3 singular-value decompositions -> scores/topology, WITH the results
+delivered to host arrays inside the step ("wall time of tq_resolve over the full batch
+incl. result D2H and, for N>1, the all-gather").  Inputs (genotype matrix, quartets) are resident in
+HBM when the timed region starts.  Every step is synchronous: when it ends, the rows are on the host
+(on rank 0 for N > 1).
 
-Workload at N=1: BASELINE.json configs[2] ("c3"): 128 taxa, 50k SNPs, 1e6 random quartets,
-subsample_snps=True (the reference's default, resolve_quartets.py:21).  Weak scaling: every
-rank resolves its own contiguous 1e6-quartet shard of an N x 1e6 global sample.
+Workloads (BASELINE.json configs):
+  N = 1  (default)      c3: 128 taxa x 50k SNPs, 1e6 random quartets, subsample_snps=True, through
+                        tq_resolve_to_host.  `--config c2|c4` select the other single-GPU shapes.
+  N > 1  (default)      c4: 256 taxa x 100k SNPs, ONE seeded sample of 5e6 quartets cut over the N ranks
+                        (strong scaling), quartet parts scanned per rank, results all-gathered (RCCL) piece by
+                        piece, regrouped into global order and copied to rank 0's host arrays.
+         --weak         every rank owns 1e6 quartets of an N x 1e6 sample of the c3 matrix.
+  --config c5           c3 shape, K bootstrap replicates: per step one replicate built on the device
+                        (locus resample + within-locus shuffle + IUPAC resolution), a fresh 1e6-quartet
+                        sample, resolve (sharded over N), gather, D2H.  RNG draws in the reference's
+                        order on one Generator (run_inference.py:378-407), made ahead by a producer thread.
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (HIP-event
-kernel time on the launch stream vs algorithmic bytes, SURVEY.md 8d: A = 4*S + 48 B/quartet)
-and `cpu_baseline` (the oracle -- a port of the reference worker -- timed on host cores).
-
-The hot path is a short kernel chain per batch: ordering (radix sort by the first two taxa) +
-tq_scan_wg_kernel (site scan -> 256 pattern counts per quartet), then the singular-value stage
-tq_bidiag_kernel + tq_bdsqr_kernel + tq_score_kernel (or tq_svd_kernel, the Jacobi path).
-`roofline.achieved` prices the algorithmic bytes against the SUM of all of them (HIP events on
-the launch stream bracket the scan stage and the singular-value stage of every pass); the two
-stage durations are listed beside it.
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (algorithmic bytes per
+launch over the HIP-event kernel time on the launch stream, SURVEY.md 8d: A = 4*S + 48 B/quartet, plus a
+per-kernel list with the fraction of the roof that actually binds each kernel) and `cpu_baseline` (the
+oracle -- a port of the reference worker -- timed on host cores; N = 1 only).
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 from pathlib import Path
@@ -34,7 +40,9 @@ import numpy as np
 REPO = Path(__file__).resolve().parent
 sys.path.insert(0, str(REPO))
 
-HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: 8.0 TB/s spec
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
+F64_VECTOR_PEAK_TFLOPS = 78.6  # 256 CU x 4 SIMD x 16 lanes x 2 flop x 2.4 GHz (tools/probe_valu.hip measures 74)
+L2_TO_CU_PEAK_GBS = 17800.0    # MI355X_MICROARCH.md "Indexed rows": rows shared out of the XCD's L2, 16.8-18.8 TB/s
 
 
 def _cpu_worker(args):
@@ -62,8 +70,7 @@ def cpu_baseline(tmparr, tmpmap, quartets, sub, gpu_rstat, gpu_rscor, budget_s=1
     cores = max(1, min(16, len(os.sched_getaffinity(0))))
     # calibrate on one core, then size the sample for ~budget_s of wall time on all cores
     dt, _, _ = _cpu_worker((tmparr, tmpmap, quartets[:300], sub))
-    per_core = 300 / dt
-    n = int(min(len(quartets), max(cores * 200, per_core * cores * budget_s)))
+    n = int(min(len(quartets), max(cores * 200, 300 / dt * cores * budget_s)))
     chunks = np.array_split(np.arange(n), cores)
     t0 = time.perf_counter()
     with mp.get_context("fork").Pool(cores) as pool:
@@ -104,7 +111,96 @@ def cpu_baseline(tmparr, tmpmap, quartets, sub, gpu_rstat, gpu_rscor, budget_s=1
                                         f"beyond one ctypes call)"),
                 sample=f"first {n} quartets of the same batch, {cores} processes x 1 thread, "
                        f"oracle.new_infer_resolved_quartets (C count loop + numpy.linalg svd/matrix_rank)",
-                per_core=per_core), parity
+                per_core=n / wall / cores), parity
+
+
+def git_head() -> str:
+    try:
+        return subprocess.check_output(["git", "-C", str(REPO), "rev-parse", "--short", "HEAD"],
+                                       stderr=subprocess.DEVNULL).decode().strip()
+    except Exception:
+        return "unknown"
+
+
+def kernel_rooflines(kms: dict, calls: int, Q: int, S: int, sub: bool, cfg: str):
+    """roofline.kernels[]: per kernel the measured ms per pass (HIP events of THIS run) and the fraction
+    (<= 1) of the roof that binds it, from a stated model of the work it has to do:
+      scan    bytes it has to pull through the L2 -> CU path (4.4 KiB per quartet and 2048-site step: 3.5 KiB
+              of its own rows c,d + a quarter of the 3.75 KiB shared (a,b) image) against the
+              fabric rate for rows served from the XCD's L2 (MI355X_MICROARCH.md);
+      bidiag  useful f64 flops of a Householder bidiagonalisation, (8/3) n^3 = 10 923 per 16x16 matrix;
+      bdsqr   useful f64 flops of the implicit-shift QR sweeps: rotation steps per matrix (measured with a
+              counting build on this workload, profiles/) x 26 flop per step
+              (two Givens generations + their applications);
+      against the f64 vector peak.  The busy-cycle counters (VALU / LDS) of the same kernels are in the
+      committed rocprofv3 --pmc summaries; `pmc` quotes them with their source file when present."""
+    calls = max(1, calls)
+    per = {k: v / calls for k, v in kms.items()}
+    out = []
+    steps = -(-S // 2048)
+    scan_bytes = Q * steps * (3.5 + 3.75 / 4) * 1024
+    if per.get("order", 0) > 0:
+        out.append(dict(name="ordering (tq_key_kernel + radix sort)", ms=per["order"], bound="latency (~20 small launches)",
+                        frac=None))
+    if per.get("scan", 0) > 0:
+        ach = scan_bytes / (per["scan"] / 1e3) / 1e9
+        out.append(dict(name="tq_scan_wg_kernel", ms=per["scan"], bound="l2->cu fabric", achieved=ach,
+                        peak=L2_TO_CU_PEAK_GBS, unit="GB/s", frac=ach / L2_TO_CU_PEAK_GBS,
+                        model="4.4 KiB per quartet-step through the L2->CU path"))
+    if per.get("bidiag", 0) > 0:
+        fl = 3 * Q * (8.0 / 3.0) * 16 ** 3
+        ach = fl / (per["bidiag"] / 1e3) / 1e12
+        out.append(dict(name="tq_bidiag_kernel", ms=per["bidiag"], bound="f64 valu", achieved=ach,
+                        peak=F64_VECTOR_PEAK_TFLOPS, unit="TFLOP/s", frac=ach / F64_VECTOR_PEAK_TFLOPS,
+                        model="(8/3)*16^3 useful flop per matrix"))
+    if per.get("bdsqr", 0) > 0:
+        steps_per_matrix = {"c3": 226.0}.get(cfg, 226.0)
+        fl = 3 * Q * steps_per_matrix * 26
+        ach = fl / (per["bdsqr"] / 1e3) / 1e12
+        out.append(dict(name="tq_bdsqr_kernel", ms=per["bdsqr"], bound="f64 valu", achieved=ach,
+                        peak=F64_VECTOR_PEAK_TFLOPS, unit="TFLOP/s", frac=ach / F64_VECTOR_PEAK_TFLOPS,
+                        model=f"{steps_per_matrix:.0f} rotation steps per matrix x 26 useful flop"))
+    if per.get("score", 0) > 0:
+        by = Q * (3 * 16 * 8 + 4 + 16 + 33)
+        ach = by / (per["score"] / 1e3) / 1e9
+        out.append(dict(name="tq_score_kernel", ms=per["score"], bound="hbm", achieved=ach, peak=HBM_PEAK_GBS,
+                        unit="GB/s", frac=ach / HBM_PEAK_GBS, model="437 B per quartet read + written"))
+    pmc = REPO / "profiles" / "pmc_busy_latest.json"
+    if pmc.exists():
+        try:
+            info = json.loads(pmc.read_text())
+            for k in out:
+                for name, v in info.get("kernels", {}).items():
+                    if name in k["name"]:
+                        k["pmc"] = dict(v, source=info.get("source"), commit=info.get("commit"))
+        except Exception:
+            pass
+    return out
+
+
+def hbm_copy_rate(torch, dev):
+    src = torch.empty(1 << 30, dtype=torch.uint8, device=dev)
+    dst = torch.empty_like(src)
+    dst.copy_(src)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(5):
+        dst.copy_(src)
+    e1.record()
+    torch.cuda.synchronize()
+    return 5 * 2 * (1 << 30) / (e0.elapsed_time(e1) / 1e3) / 1e9
+
+
+def c5_source(synth, bootstrap):
+    """The project's `seqarr` (ASCII, 1 % IUPAC two-base codes) and locus spans for the c5 shape."""
+    T, S, _ = synth.CONFIGS["c3"]
+    tmparr, tmpmap = synth.simulate_tmparr(T, S, synth.CONFIG_SEEDS["c5"])
+    ascii_ = np.array([65, 67, 71, 84], np.uint8)
+    seqarr = np.where(tmparr <= 3, ascii_[np.minimum(tmparr, 3)], 78).astype(np.uint8)
+    rs = np.random.default_rng(0)
+    amb = rs.random(seqarr.shape) < 0.01
+    seqarr[amb] = rs.choice(np.array([82, 75, 83, 89, 87, 77], np.uint8), size=int(amb.sum()))
+    return seqarr, bootstrap.get_spans(tmpmap), T, S
 
 
 def main():
@@ -112,21 +208,25 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--config", default="c3", choices=["c2", "c3", "c4"])
-    ap.add_argument("--quartets", type=int, default=0, help="quartets per GPU (0 = config default)")
+    ap.add_argument("--config", default=None, choices=["c2", "c3", "c4", "c5"],
+                    help="default: c3 on one GPU, c4 (strong scaling) on several")
+    ap.add_argument("--weak", action="store_true", help="N > 1: every rank its own 1e6 quartets of the c3 matrix")
+    ap.add_argument("--quartets", type=int, default=0, help="quartets in the batch (0 = config default)")
     ap.add_argument("--full", action="store_true", help="subsample_snps=False")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo = rehearsal of the N>1 control flow on a box with fewer GPUs than ranks")
-    ap.add_argument("--nrep", type=int, default=0)
-    ap.add_argument("--order", type=int, default=-1, help="0 = natural quartet order, 1 = (a,b)-sorted (default)")
-    ap.add_argument("--waves-per-cu", type=int, default=0)
+    ap.add_argument("--pieces", type=int, default=0, help="N > 1: result pieces per batch (0 = automatic)")
+    ap.add_argument("--sampler", default="host", choices=["host", "device"],
+                    help="c5: quartet sample drawn on the project Generator (reference stream) or on the device")
+    ap.add_argument("--svd-chunk", type=int, default=0)
+    ap.add_argument("--order", type=int, default=-1, help="0 = natural quartet order, 1 = sorted (default)")
     ap.add_argument("--phases", type=int, default=0, help="diagnostic: 1 scan only, 2 SVD only (invalid as a result)")
     args = ap.parse_args()
 
     import torch
     from tetrad_amd import synth
-    from tetrad_amd.engine import QuartetEngine
+    from tetrad_amd.engine import QuartetEngine, pinned_empty
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -145,149 +245,282 @@ def main():
         else:
             dist.init_process_group("gloo")
 
-    T, S, qdef = synth.CONFIGS[args.config]
+    cfg = args.config or ("c3" if world == 1 else ("c3" if args.weak else "c4"))
+    if args.weak and cfg != "c3":
+        raise SystemExit("--weak is the c3 shape")
     sub = not args.full
-    tmparr, tmpmap = synth.simulate_tmparr(T, S, synth.CONFIG_SEEDS[args.config])
-    Q = args.quartets or qdef or int(synth.comb(T, 4))
-    if qdef is None and not args.quartets:
-        quartets = synth.all_quartets(T)
-    else:
-        # one global sample of world*Q quartets, rank r owns the contiguous slice [r*Q, (r+1)*Q)
-        idx = np.random.default_rng(synth.CONFIG_SEEDS[args.config] + 1000).choice(
-            synth.comb(T, 4), size=world * Q, replace=False)
-        quartets = synth.unrank_quartets(idx[rank * Q:(rank + 1) * Q], T)
-
     eng = QuartetEngine(dev_index)
-    if args.nrep:
-        eng.set_option("nrep", args.nrep)
-    if args.waves_per_cu:
-        eng.set_option("waves_per_cu", args.waves_per_cu)
     if args.phases:
         eng.set_option("phases", args.phases)
     if args.order >= 0:
         eng.set_option("order", args.order)
+    if args.svd_chunk:
+        eng.set_option("svd_chunk", args.svd_chunk)
+
+    if cfg == "c5":
+        return bench_c5(args, eng, torch, dist, dev, world, rank)
+
+    T, S, qdef = synth.CONFIGS[cfg]
+    tmparr, tmpmap = synth.simulate_tmparr(T, S, synth.CONFIG_SEEDS[cfg])
     eng.set_data(tmparr, tmpmap)
-
-    d_q = torch.from_numpy(quartets.astype(np.int32)).to(dev)
-    # two sets of output buffers: for N > 1 the all-gather of pass i runs (on RCCL's stream) while
-    # the kernels of pass i+1 write the other set
-    nbuf = 2 if world > 1 else 1
-    # one contiguous 32-byte-per-quartet slab per buffer set: [rstat u32[Q,2] | rscor f64[Q,3]], so that the
-    # result gather is ONE collective per step with no packing kernel (fixed-size records)
-    d_outs = [torch.zeros(32 * Q, dtype=torch.uint8, device=dev) for _ in range(nbuf)]
-    d_rstats = [o[:8 * Q].view(torch.int32).view(Q, 2) for o in d_outs]
-    d_rscors = [o[8 * Q:].view(torch.float64).view(Q, 3) for o in d_outs]
-    d_flags = torch.zeros(Q, dtype=torch.uint8, device=dev)
-    gdev = dev if args.backend == "nccl" else torch.device("cpu")
-    if world > 1:
-        g_outs = [torch.zeros(world * 32 * Q, dtype=torch.uint8, device=gdev) for _ in range(nbuf)]
+    lexi = qdef is None and not args.quartets
+    if lexi:
+        Q = int(synth.comb(T, 4))
+        ranks_all = np.arange(Q, dtype=np.int64)
+    else:
+        Q = args.quartets or qdef
+        if args.weak:
+            Q *= world
+        # ONE seeded sample for the whole job, identical on every rank (combinations.py:109-114)
+        ranks_all = np.random.default_rng(synth.CONFIG_SEEDS[cfg] + 1000).choice(
+            synth.comb(T, 4), size=Q, replace=False).astype(np.int64)
     stream = torch.cuda.current_stream().cuda_stream
-    pending = [[], []]
-    counter = [0]
 
-    def step():
-        b = counter[0] % nbuf
-        counter[0] += 1
-        for w in pending[b]:           # the gather that last read this buffer set must be done
-            w.wait()
-        pending[b] = []
-        eng.resolve_dev(d_q.data_ptr(), Q, sub, d_rstats[b].data_ptr(), d_rscors[b].data_ptr(),
-                        d_flags.data_ptr(), stream)
-        if world > 1:
-            # result gather: every rank ends up with the whole node's rows in global order
-            pending[b] = [dist.all_gather_into_tensor(g_outs[b], d_outs[b].to(gdev), async_op=True)]
-
-    def fence():
-        for ws in pending:
-            for w in ws:
-                w.wait()
-            ws.clear()
+    def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
+    extra = {}
+    if world == 1:
+        d_r = torch.from_numpy(ranks_all).to(dev)
+        d_q = torch.empty((Q, 4), dtype=torch.int32, device=dev)
+        eng.unrank_dev(d_r.data_ptr(), Q, d_q.data_ptr(), stream)
+        torch.cuda.synchronize()
+        out = (pinned_empty((Q, 2), np.uint32), pinned_empty((Q, 3), np.float64), pinned_empty(Q, np.uint8))
+
+        def step():
+            eng.resolve_to_host(d_q.data_ptr(), Q, sub, out=out)
+
+        def results():
+            return out
+    else:
+        from tetrad_amd.distributor import ShardedResolver
+        res = ShardedResolver(Q, engine=eng, device=dev_index, dst=0, pieces=args.pieces or None)
+        res.set_ranks(ranks_all)
+        torch.cuda.synchronize()
+        last = [None]
+
+        def step():
+            res.start(sub)
+            last[0] = res.finish()
+
+        def results():
+            return last[0]
+
     for _ in range(args.warmup):
         step()
-    fence()
+    barrier()
     eng.timing_enable(True)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-    fence()
+    barrier()
     elapsed = time.perf_counter() - t0
-    kernel_ms, scan_ms, svd_ms, launches = eng.timing_read_split()
+    kms, launches = eng.timing_read_kernels()
+    # per-kernel durations of the singular-value stage: in the timed region two chunks run concurrently on
+    # two streams (one chunk's tail is filled by the next), so their event spans overlap; three more steps
+    # with the chunks serialised on one stream give each kernel's own duration for roofline.kernels[]
+    eng.set_option("svd_streams", 1)
+    step()
+    eng.timing_read_kernels()
+    for _ in range(3):
+        step()
+    kms_serial, launches_serial = eng.timing_read_kernels()
+    eng.set_option("svd_streams", 0)
     eng.timing_enable(False)
     if world > 1:
+        gdev = dev if args.backend == "nccl" else torch.device("cpu")
         t = torch.tensor([elapsed], dtype=torch.float64, device=gdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    step()                                  # results of the default configuration
 
-    # PCIe-inclusive rate of the host-buffer API (quartets H2D + results D2H per call); reported
-    # beside `value`, never as `value`
-    eng.resolve(quartets, sub)          # first call allocates the host-API scratch
-    t1 = time.perf_counter()
-    eng.resolve(quartets, sub)
-    pcie_inclusive = Q / (time.perf_counter() - t1)
-
-    # device-to-device copy rate of this GPU (what "8 TB/s" means in practice here; SURVEY 8d asks
-    # for the vendor figure and a measured one side by side): 1 GiB read + 1 GiB written per copy
-    hbm_copy = None
-    if rank == 0:
-        src = torch.empty(1 << 30, dtype=torch.uint8, device=dev)
-        dst = torch.empty_like(src)
-        dst.copy_(src)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(5):
-            dst.copy_(src)
-        e1.record()
+    rstat, rscor, flags = results()
+    if world == 1:
+        # device-resident rate (no result D2H) and the PCIe-inclusive rate of the host-buffer API (quartets
+        # H2D from a page-locked array + results D2H per call); reported beside `value`, never as `value`
+        quartets_h = pinned_empty((Q, 4), np.uint32)
+        quartets_h[...] = d_q.cpu().numpy().view(np.uint32)
+        d_rstat = torch.zeros((Q, 2), dtype=torch.int32, device=dev)
+        d_rscor = torch.zeros((Q, 3), dtype=torch.float64, device=dev)
+        d_flags = torch.zeros(Q, dtype=torch.uint8, device=dev)
+        eng.resolve_dev(d_q.data_ptr(), Q, sub, d_rstat.data_ptr(), d_rscor.data_ptr(), d_flags.data_ptr(), stream)
         torch.cuda.synchronize()
-        hbm_copy = 5 * 2 * (1 << 30) / (e0.elapsed_time(e1) / 1e3) / 1e9
-        del src, dst
+        t1 = time.perf_counter()
+        for _ in range(3):
+            eng.resolve_dev(d_q.data_ptr(), Q, sub, d_rstat.data_ptr(), d_rscor.data_ptr(), d_flags.data_ptr(), stream)
+        torch.cuda.synchronize()
+        extra["device_resident_value"] = 3 * Q / (time.perf_counter() - t1)
+        eng.resolve(quartets_h, sub)
+        t1 = time.perf_counter()
+        for _ in range(3):
+            r_h = eng.resolve(quartets_h, sub)
+        extra["pcie_inclusive_value"] = 3 * Q / (time.perf_counter() - t1)
+        extra["host_api_equals_timed_path"] = bool(np.array_equal(r_h[0], rstat) and np.array_equal(r_h[1], rscor))
+        q_pageable = np.array(quartets_h)
+        out_pg = (np.empty((Q, 2), np.uint32), np.empty((Q, 3), np.float64), np.empty(Q, np.uint8))
+        import ctypes
+        def pageable_call():
+            rc = eng._lib.tq_resolve(eng._h, ctypes.c_void_p(q_pageable.ctypes.data), Q, int(sub),
+                                     ctypes.c_void_p(out_pg[0].ctypes.data), ctypes.c_void_p(out_pg[1].ctypes.data),
+                                     ctypes.c_void_p(out_pg[2].ctypes.data))
+            assert rc == 0
+        pageable_call()
+        t1 = time.perf_counter()
+        for _ in range(3):
+            pageable_call()
+        extra["pcie_inclusive_value_pageable_arrays"] = 3 * Q / (time.perf_counter() - t1)
+    else:
+        # the gathered rows on rank 0 against what every rank computed itself: a checksum over each rank's
+        # own rows and 64 sampled rows per rank, compared bit for bit
+        P = res.plan
+        own = res.device_rows()
+        idx = torch.from_numpy(P.local_index(rank)).to(own[0].device)
+        mine = [x.index_select(0, idx) for x in own] if len(idx) else None
+        pick = np.random.default_rng(rank).integers(0, max(1, len(idx)), size=min(64, len(idx)))
+        rec = dict(rank=rank, n=int(len(idx)),
+                   nsnps_sum=int(mine[0][:, 1].to(torch.int64).sum().item()) if mine else 0,
+                   score_bits_xor=int(np.bitwise_xor.reduce(mine[1].cpu().numpy().view(np.int64).ravel())) if mine else 0,
+                   rows=[(int(P.local_index(rank)[i]), mine[0][i].tolist(), mine[1][i].cpu().numpy().view(np.int64).tolist())
+                         for i in pick] if mine else [])
+        recs = [None] * world
+        dist.all_gather_object(recs, rec)
+        if rank == 0:
+            ok = True
+            for r in recs:
+                gi = P.local_index(r["rank"])
+                ok &= int(rstat[gi, 1].astype(np.int64).sum()) == r["nsnps_sum"]
+                ok &= int(np.bitwise_xor.reduce(rscor[gi].view(np.int64).ravel())) == r["score_bits_xor"] if len(gi) else True
+                for g, rs, sc in r["rows"]:
+                    ok &= rstat[g].astype(np.int64).tolist() == [x & 0xFFFFFFFF for x in rs]
+                    ok &= rscor[g].view(np.int64).tolist() == sc
+            extra["gather_verified"] = bool(ok)
+            extra["gather_pieces"] = P.npieces
+            extra["rows_per_piece_per_rank"] = P.part
 
-    last = (counter[0] - 1) % nbuf
-    rstat = d_rstats[last].cpu().numpy().astype(np.uint32)
-    rscor = d_rscors[last].cpu().numpy()
-    flags = d_flags.cpu().numpy()
+    hbm_copy = hbm_copy_rate(torch, dev) if rank == 0 else None
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
-        value = world * Q * args.steps / elapsed
+        value = Q * args.steps / elapsed
         A = 4 * S + 48                                   # algorithmic bytes per quartet
-        bytes_per_launch = Q * A + 4 * S
-        avg_kernel_s = kernel_ms / max(1, launches) / 1e3
-        achieved = bytes_per_launch / avg_kernel_s / 1e9
-        traffic = None
-        tf = REPO / "profiles" / f"traffic_{args.config}_{'sub' if sub else 'full'}.json"
-        if tf.exists():
-            traffic = json.loads(tf.read_text()).get("hbm_bytes_per_launch")
+        q_rank = res.n_local if world > 1 else Q           # quartets one launch of the scan kernel covers here
+        bytes_per_launch = q_rank * A + 4 * S
+        per_pass = {k: v / max(1, launches) for k, v in kms.items()}
+        dominant_ms = per_pass["scan"]
+        achieved = bytes_per_launch / (dominant_ms / 1e3) / 1e9
+        traffic, traffic_src = None, "not measured in this run"
+        tf = REPO / "profiles" / f"traffic_{cfg}_{'sub' if sub else 'full'}.json"
+        if tf.exists() and world == 1 and not args.quartets:
+            tj = json.loads(tf.read_text())
+            traffic = tj.get("hbm_bytes_per_launch")
+            traffic_src = (f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, collated in {tf.name} "
+                           f"(commit {tj.get('commit', 'unknown')}); not re-measured in this run")
+        what = ("lexicographic (all)" if lexi else "random")
+        workload = (f"{cfg}: {T} taxa x {S} SNPs, {Q} {what} quartets"
+                    + (f" in one batch cut over {world} GPUs (strong scaling)" if world > 1 and not args.weak else "")
+                    + (f" = {Q // world} per GPU (weak scaling)" if args.weak else "")
+                    + f", subsample_snps={sub}, results delivered to host arrays inside the step")
         line = {
             "metric": "resolved quartets/sec (whole node)", "value": value, "unit": "quartets/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": "weak" if (args.weak or world == 1) else "strong",
+            "vs_baseline": None,
             "dtype": "u8 scan / u32 counts / f64 SVD", "data": "synthetic",
-            "config": {"workload": f"{args.config}: {T} taxa x {S} SNPs, {Q} {'random' if (qdef or args.quartets) else 'lexicographic (all)'} quartets per GPU, "
-                                   f"subsample_snps={sub}", "quartets_per_gpu": Q, "taxa": T, "snps": S,
-                       "subsample_snps": sub, "parallelism": f"quartet-sharded x{world} + all-gather"},
+            "config": {"workload": workload, "quartets": Q, "taxa": T, "snps": S, "subsample_snps": sub,
+                       "parallelism": (f"quartet-sharded x{world}, one all-gather per result piece, rows to rank 0's host"
+                                       if world > 1 else "one GPU, result D2H overlapped inside tq_resolve_to_host")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "frac": achieved / HBM_PEAK_GBS,
+                         "note": ("algorithmic bytes (SURVEY 8d: 4*S+48 per quartet) over the dominant kernel's time; the "
+                                  "genotype matrix is L2 / Infinity-Cache resident, so this exceeds the HBM peak and is NOT an "
+                                  "efficiency figure -- see kernels[].frac for each kernel against the roof that binds it"),
+                         "kernel": "tq_scan_wg_kernel", "kernel_ms": dominant_ms,
+                         "algorithmic_bytes_per_launch": bytes_per_launch,
+                         "traffic": traffic, "traffic_source": traffic_src,
                          "hbm_copy_measured_GBs": hbm_copy,
-                         "kernel": "one pass of the hot path: tq_scan_wg_kernel (+ordering) then tq_bidiag/tq_bdsqr/tq_score",
-                         "kernel_ms": kernel_ms / max(1, launches),
-                         "scan_stage_ms": scan_ms / max(1, launches),
-                         "svd_stage_ms": svd_ms / max(1, launches),
-                         "achieved_scan_stage_only": bytes_per_launch / (scan_ms / max(1, launches) / 1e3) / 1e9,
-                         "algorithmic_bytes_per_launch": bytes_per_launch},
-            "pcie_inclusive_value_per_gpu": pcie_inclusive,
-            "flags": {"zero_data": int((flags & 1).sum()), "degenerate": int(((flags & 2) > 0).sum())},
+                         "scan_stage_ms_per_step": per_pass["order"] + per_pass["scan"],
+                         "kernels_note": ("ms of each kernel per step from 3 extra steps of this run with the singular-value "
+                                          "chunks serialised on one stream; in the timed region two chunks overlap on two "
+                                          "streams (sum of their event spans per step: "
+                                          f"{per_pass['bidiag'] + per_pass['bdsqr'] + per_pass['score']:.3f} ms)"),
+                         "kernels": kernel_rooflines(kms_serial, launches_serial, q_rank, S, sub, cfg)},
+            "flags": {"zero_data": int((flags & 1).sum()), "degenerate": int(((flags & 2) > 0).sum()),
+                      "no_convergence": int(((flags & 8) > 0).sum())},
+            "commit": git_head(),
         }
+        line.update(extra)
         if args.phases in (1, 2):
             line["INVALID_diagnostic_phases"] = args.phases
         if not args.no_cpu and args.phases in (0, 3) and world == 1:     # CPU leg: rank 0 at N=1 only
-            cb, parity = cpu_baseline(tmparr, tmpmap, quartets, sub, rstat, rscor)
+            quartets_np = np.array(quartets_h)
+            cb, parity = cpu_baseline(tmparr, tmpmap, quartets_np, sub, rstat, rscor)
             line["cpu_baseline"] = cb
             line["parity_on_cpu_sample"] = parity
             line["gpu_over_cpu"] = value / cb["value"]
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def bench_c5(args, eng, torch, dist, dev, world, rank):
+    from tetrad_amd.replicates import ReplicateRunner
+    from tetrad_amd import bootstrap, synth
+    seqarr, spans, T, S0 = c5_source(synth, bootstrap)
+    Q = args.quartets or 1_000_000
+    runner = ReplicateRunner(eng, seqarr, spans, Q, seed=synth.CONFIG_SEEDS["c5"], sampler=args.sampler,
+                             pieces=args.pieces or None)
+    sub = not args.full
+    for _ in range(args.warmup):
+        runner.run(1, sub)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    eng.timing_enable(True)
+    t0 = time.perf_counter()
+    stats = runner.run(args.steps, sub)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    kms, launches = eng.timing_read_kernels()
+    eng.timing_enable(False)
+    if world > 1:
+        gdev = dev if args.backend == "nccl" else torch.device("cpu")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=gdev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    runner.close()
+    if rank == 0:
+        S = int(np.mean(stats["sites"]))
+        q_rank = runner.n_local
+        A = 4 * S + 48
+        per_pass = {k: v / max(1, launches) for k, v in kms.items()}
+        bytes_per_launch = q_rank * A + 4 * S
+        achieved = bytes_per_launch / (per_pass["scan"] / 1e3) / 1e9
+        line = {
+            "metric": "resolved quartets/sec (whole node)", "value": Q * args.steps / elapsed, "unit": "quartets/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "u8 scan / u32 counts / f64 SVD", "data": "synthetic",
+            "config": {"workload": f"c5: {T} taxa x {S0} source SNPs, {args.steps} bootstrap replicates (one per step): device "
+                                   f"locus resample + column shuffle + IUPAC resolution, fresh sample of {Q} quartets per "
+                                   f"replicate cut over {world} GPU(s), subsample_snps={sub}, rows delivered to rank 0's host",
+                       "quartets_per_replicate": Q, "taxa": T, "snps": S0, "mean_replicate_sites": S,
+                       "subsample_snps": sub, "sampler": args.sampler,
+                       "parallelism": f"replicate-sequential RNG (run_inference.py:378-407), quartet-sharded x{world}"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "kernel": "tq_scan_wg_kernel", "kernel_ms": per_pass["scan"],
+                         "algorithmic_bytes_per_launch": bytes_per_launch, "traffic": None,
+                         "traffic_source": "not measured in this run",
+                         "all_kernels_ms_per_step": sum(per_pass.values()),
+                         "kernels": kernel_rooflines(kms, launches, q_rank, S, sub, "c3")},
+            "host_ms_per_replicate": stats["host_ms"],
+            "flags": stats["flags"], "rng_state_matches_reference_draw_order": stats.get("rng_check"),
+            "commit": git_head(),
+        }
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

@@ -1,4 +1,4 @@
-"""Host logic of the multi-GPU path on CPU: sharding, record packing, world_size-2 gloo gather,
+"""Host logic of the multi-GPU path on CPU: sharding plan, world_size-2 gloo gather and regrouping,
 TSV text.  The per-rank compute step is the oracle here (test infrastructure); on a GPU box the
 default compute is the HIP engine (tests/test_gpu_parity.py covers that path)."""
 import os
@@ -33,18 +33,46 @@ def test_get_chunksize_matches_reference_rule():
     assert D.get_chunksize(3, 80) == 3
 
 
-def test_record_roundtrip_is_bit_exact():
-    rng = np.random.default_rng(0)
-    n = 1000
-    rstat = np.stack([rng.integers(0, 3, n), rng.integers(0, 2**32, n)], axis=1).astype(np.uint32)
-    rscor = rng.standard_normal((n, 3)) * 10.0 ** rng.integers(-300, 300, (n, 3))
-    rscor[0] = [0.001, np.inf, -0.0]
-    rscor[1, 0] = np.nan
-    flags = rng.integers(0, 8, n).astype(np.uint8)
-    a, b, c = D.unpack_records(D.pack_records(rstat, rscor, flags))
-    np.testing.assert_array_equal(a, rstat)
-    np.testing.assert_array_equal(b.view(np.int64), rscor.view(np.int64))
-    np.testing.assert_array_equal(c, flags)
+def test_shard_plan_covers_every_row_once():
+    """Pieces x per-rank parts tile [0,Q) exactly; the gathered slab of a piece never reaches beyond the
+    slack rows; the processing order of a rank is its parts in piece order."""
+    for Q in (1, 2, 7, 101, 1820, 1_000_003):
+        for w in (1, 2, 3, 8):
+            for pieces in (None, 1, 2, 5, 8, 50):
+                P = D.ShardPlan(Q, w, pieces)
+                assert 1 <= P.npieces <= min(8, Q)
+                seen = np.zeros(Q, np.int32)
+                for r in range(w):
+                    idx = P.local_index(r)
+                    seen[idx] += 1
+                    assert (np.diff(idx) > 0).all()
+                assert (seen == 1).all()
+                for i in range(P.npieces):
+                    assert P.start[i] + w * P.part[i] <= P.rows_padded
+                    assert w * P.part[i] >= P.end[i] - P.start[i]
+                    assert P.slab_bytes(i) >= 33 * P.part[i] and P.slab_bytes(i) % 16 == 0
+                    # part r of piece i holds global rows start + r*part + k
+                    for r in range(w):
+                        lo, hi = P.part_range(i, r)
+                        assert lo == min(P.start[i] + r * P.part[i], P.end[i]) and lo <= hi <= P.end[i]
+
+
+def test_single_process_resolver_with_injected_compute(oracle):
+    """world = 1, host compute: the piece / regroup logic alone (several pieces, ragged last part)."""
+    g = load_golden("tree_T12_S2000")
+    q = g["quartets"][:97]
+
+    def compute(ql, sub):
+        _, rstat, rscor, dbg = oracle.new_infer_resolved_quartets(g["tmparr"], g["tmpmap"], ql, sub, debug=True)
+        return rstat, rscor, dbg["flags"]
+
+    want = compute(q, True)
+    for pieces in (1, 3, 8):
+        res = D.ShardedResolver(len(q), compute=compute, pieces=pieces)
+        res.set_quartets(q)
+        got = res.resolve(True)
+        for a, b in zip(want, got):
+            np.testing.assert_array_equal(a, b)
 
 
 def test_tsv_text_equals_reference_pandas_call():
@@ -74,6 +102,12 @@ def compute(tmparr, tmpmap, q, sub):
 qr = g["quartets"][:101]                       # odd count: exercises the padded slab
 _, rstat, rscor, flags = D.resolve_sharded(g["tmparr"], g["tmpmap"], qr, True, compute=compute)
 np.savez(out + f".{rank}.npz", rstat=rstat, rscor=rscor, flags=flags)
+# several pieces (one all-gather each), rows to rank 0 only
+_, rstat3, rscor3, flags3 = D.resolve_sharded(g["tmparr"], g["tmpmap"], qr, True, compute=compute, pieces=3, dst=0)
+if rank == 0:
+    np.savez(out + ".p3.npz", rstat=rstat3, rscor=rscor3, flags=flags3)
+else:
+    assert rstat3 is None and rscor3 is None and flags3 is None
 # file-writing mirror of run_inference.distributor: only rank 0 writes
 db = out + ".db.npz"
 if rank == 0:
@@ -107,6 +141,9 @@ def test_two_rank_gloo_gather_equals_single_rank(tmp_path, oracle):
         z = np.load(out + f".{r}.npz")
         np.testing.assert_array_equal(z["rstat"], rstat)              # N-rank == 1-rank, bitwise
         np.testing.assert_array_equal(z["rscor"], rscor)
+    z = np.load(out + ".p3.npz")
+    np.testing.assert_array_equal(z["rstat"], rstat)
+    np.testing.assert_array_equal(z["rscor"], rscor)
     # rank 0 wrote all chunks in order, 9 columns
     rows = Path(out + ".tsv").read_text().splitlines()
     assert len(rows) == 101

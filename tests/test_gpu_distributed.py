@@ -28,7 +28,7 @@ dist.init_process_group("gloo", rank=rank, world_size=world)
 g = np.load(os.path.join(sys.argv[1], "tests", "golden", "c1_T16_S5000.npz"))
 qr = g["quartets"][:1501]                      # odd count: exercises the padded slab
 for sub in (True, False):
-    _, rstat, rscor, flags = D.resolve_sharded(g["tmparr"], g["tmpmap"], qr, sub)
+    _, rstat, rscor, flags = D.resolve_sharded(g["tmparr"], g["tmpmap"], qr, sub, pieces=(3 if sub else None))
     np.savez(out + f".{int(sub)}.{rank}.npz", rstat=rstat, rscor=rscor, flags=flags)
 db = out + ".db.npz"
 if rank == 0:

@@ -102,7 +102,11 @@ struct tq_ctx {
     double *d_de = nullptr, *d_sv = nullptr;
     uint32_t *d_nsnps = nullptr;
     int64_t svd_quartets = 0;
-    int64_t svd_chunk = 1 << 17;    // quartets per pass of the singular-value stage (and per result D2H piece)
+    int64_t svd_chunk = 1 << 18;    // quartets per pass of the singular-value stage (and per result D2H piece)
+    int svd_streams = 2;            // chunks alternate between this many streams (1 or 2) so that the tail of one
+                                    // chunk's kernels is filled by the next chunk's (each stream has its own scratch)
+    hipStream_t sX = nullptr;       // the second stream of the singular-value stage
+    hipEvent_t evFork = nullptr, evJoin = nullptr;
     int svd_method = 1;             // 0 = one-sided Jacobi (tq_svd_kernel), 1 = Householder + bidiagonal QR
     int bdsqr_maxit = 60;           // QR sweeps per singular value before a matrix is declared not converged
     int scan_wg = 4;                // waves per workgroup of the cooperative scan kernel (1 = one wave per quartet)
@@ -123,7 +127,7 @@ struct tq_ctx {
     // timing: a sequence of tagged HIP events on the launch stream; the time between two consecutive
     // marks is attributed to the tag of the later one (TAG_ORIGIN starts a sequence)
     bool timing = false;
-    struct Mark { int tag; hipEvent_t ev; };
+    struct Mark { int tag; int lane; hipEvent_t ev; };      // lane: 0 = caller's stream, 1 = sX
     std::vector<Mark> marks;
     std::vector<hipEvent_t> event_pool;
     int64_t timed_calls = 0;
@@ -311,9 +315,14 @@ int ensure_cm(tq_ctx *ctx, int64_t quartets)
     return TQ_OK;
 }
 
-// scratch of the singular-value stage for one chunk of `quartets`
+// scratch of the singular-value stage: two sets (one per stream) for chunks of `quartets`
 int ensure_svd(tq_ctx *ctx, int64_t quartets)
 {
+    if (!ctx->sX) {
+        TQ_HIP(ctx, hipStreamCreateWithFlags(&ctx->sX, hipStreamNonBlocking));
+        TQ_HIP(ctx, hipEventCreateWithFlags(&ctx->evFork, hipEventDisableTiming));
+        TQ_HIP(ctx, hipEventCreateWithFlags(&ctx->evJoin, hipEventDisableTiming));
+    }
     if (quartets <= ctx->svd_quartets) return TQ_OK;
     if (ctx->d_de) (void)hipFree(ctx->d_de);
     if (ctx->d_sv) (void)hipFree(ctx->d_sv);
@@ -321,15 +330,15 @@ int ensure_svd(tq_ctx *ctx, int64_t quartets)
     ctx->d_de = ctx->d_sv = nullptr;
     ctx->d_nsnps = nullptr;
     ctx->svd_quartets = 0;
-    TQ_HIP(ctx, hipMalloc((void **)&ctx->d_de, (size_t)quartets * 3 * 32 * sizeof(double)));
-    TQ_HIP(ctx, hipMalloc((void **)&ctx->d_sv, (size_t)quartets * 3 * 16 * sizeof(double)));
-    TQ_HIP(ctx, hipMalloc((void **)&ctx->d_nsnps, (size_t)quartets * sizeof(uint32_t)));
+    TQ_HIP(ctx, hipMalloc((void **)&ctx->d_de, 2 * (size_t)quartets * 3 * 32 * sizeof(double)));
+    TQ_HIP(ctx, hipMalloc((void **)&ctx->d_sv, 2 * (size_t)quartets * 3 * 16 * sizeof(double)));
+    TQ_HIP(ctx, hipMalloc((void **)&ctx->d_nsnps, 2 * (size_t)quartets * sizeof(uint32_t)));
     ctx->svd_quartets = quartets;
     return TQ_OK;
 }
 
 // ---- timing marks -------------------------------------------------------------------------------
-int mark(tq_ctx *ctx, int tag, hipStream_t stream)
+int mark(tq_ctx *ctx, int tag, hipStream_t stream, int lane = 0)
 {
     if (!ctx->timing) return TQ_OK;
     hipEvent_t ev;
@@ -340,7 +349,7 @@ int mark(tq_ctx *ctx, int tag, hipStream_t stream)
         TQ_HIP(ctx, hipEventCreate(&ev));
     }
     try {
-        ctx->marks.push_back({tag, ev});
+        ctx->marks.push_back({tag, lane, ev});
     } catch (...) {
         (void)hipEventDestroy(ev);
         return fail(ctx, TQ_ERR_OOM, "out of host memory");
@@ -483,7 +492,8 @@ int launch_scan_n(tq_ctx *ctx, const uint32_t *dq, const uint32_t *order, int64_
 
 // Jacobi path: count slab rows [cm, cm + n) -> outputs of the same rows
 template <bool DEBUG>
-int launch_svd(tq_ctx *ctx, const uint32_t *cm, const uint32_t *dq, int64_t n, const OutPtrs &out, hipStream_t stream)
+int launch_svd(tq_ctx *ctx, const uint32_t *cm, const uint32_t *dq, int64_t n, const OutPtrs &out, hipStream_t stream,
+               int lane)
 {
     auto kern = tq_svd_kernel<DEBUG>;
     int64_t grid;
@@ -491,13 +501,18 @@ int launch_svd(tq_ctx *ctx, const uint32_t *cm, const uint32_t *dq, int64_t n, c
     if (rc) return rc;
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(WAVE), 0, stream, cm, dq, n, (int32_t)ctx->T, out);
     TQ_HIP(ctx, hipGetLastError());
-    return mark(ctx, TAG_BIDIAG, stream);
+    return mark(ctx, TAG_BIDIAG, stream, lane);
 }
 
 // Householder + QR path, one chunk (n <= svd scratch)
 template <bool DEBUG>
-int launch_hqr(tq_ctx *ctx, const uint32_t *cm, const uint32_t *dq, int64_t n, const OutPtrs &out, hipStream_t stream)
+int launch_hqr(tq_ctx *ctx, const uint32_t *cm, const uint32_t *dq, int64_t n, const OutPtrs &out, hipStream_t stream,
+               int lane)
 {
+    // scratch set of this stream
+    double *de = ctx->d_de + (size_t)lane * (size_t)ctx->svd_quartets * 96;
+    double *sv = ctx->d_sv + (size_t)lane * (size_t)ctx->svd_quartets * 48;
+    uint32_t *nsnps = ctx->d_nsnps + (size_t)lane * (size_t)ctx->svd_quartets;
     int64_t grid;
     auto k1 = tq_bidiag_kernel<DEBUG>;
     // one pass per block unless told otherwise: the work per pass varies (QR iterations), and the
@@ -505,20 +520,20 @@ int launch_hqr(tq_ctx *ctx, const uint32_t *cm, const uint32_t *dq, int64_t n, c
     const int svd_wpc = ctx->svd_wpc > 0 ? ctx->svd_wpc : (1 << 20);
     int rc = grid_for(ctx, k1, (n + 15) / 16, &grid, svd_wpc);
     if (rc) return rc;
-    hipLaunchKernelGGL(k1, dim3((unsigned)grid), dim3(WAVE), 0, stream, cm, n, ctx->d_de, ctx->d_nsnps, out.cmats);
+    hipLaunchKernelGGL(k1, dim3((unsigned)grid), dim3(WAVE), 0, stream, cm, n, de, nsnps, out.cmats);
     TQ_HIP(ctx, hipGetLastError());
-    if ((rc = mark(ctx, TAG_BIDIAG, stream))) return rc;
+    if ((rc = mark(ctx, TAG_BIDIAG, stream, lane))) return rc;
     const int64_t nmat = 3 * n;
     rc = grid_for(ctx, tq_bdsqr_kernel, (nmat + WAVE - 1) / WAVE, &grid, svd_wpc);
     if (rc) return rc;
-    hipLaunchKernelGGL(tq_bdsqr_kernel, dim3((unsigned)grid), dim3(WAVE), 0, stream, (const double *)ctx->d_de, nmat,
-                       ctx->d_sv, ctx->bdsqr_maxit);
+    hipLaunchKernelGGL(tq_bdsqr_kernel, dim3((unsigned)grid), dim3(WAVE), 0, stream, (const double *)de, nmat, sv,
+                       ctx->bdsqr_maxit);
     TQ_HIP(ctx, hipGetLastError());
-    if ((rc = mark(ctx, TAG_BDSQR, stream))) return rc;
+    if ((rc = mark(ctx, TAG_BDSQR, stream, lane))) return rc;
     hipLaunchKernelGGL(tq_score_kernel<DEBUG>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream,
-                       (const double *)ctx->d_sv, (const uint32_t *)ctx->d_nsnps, dq, n, (int32_t)ctx->T, out);
+                       (const double *)sv, (const uint32_t *)nsnps, dq, n, (int32_t)ctx->T, out);
     TQ_HIP(ctx, hipGetLastError());
-    return mark(ctx, TAG_SCORE, stream);
+    return mark(ctx, TAG_SCORE, stream, lane);
 }
 
 OutPtrs offset_out(const OutPtrs &o, int64_t q0)
@@ -564,9 +579,12 @@ int stage_scan(tq_ctx *ctx, const uint32_t *dq, int64_t n, int subsample, bool i
 }
 
 // Stage 2 of a pass: singular values, ranks, scores and topology of rows [q0, q0+n) of the scanned
-// batch, in chunks of svd_chunk quartets.  `out` points at the outputs of row q0.  After each chunk
-// `after_chunk(c0, cn)` is called (c0 relative to q0) with the chunk's kernels enqueued: the host-buffer
-// API starts that chunk's result D2H there.
+// batch, in chunks of svd_chunk quartets.  `out` points at the outputs of row q0.  Chunks alternate
+// between the caller's stream and a second one (each with its own scratch set), so that the tail of one
+// chunk's kernels -- a wave per 64 matrices with data-dependent iteration counts -- is filled by the next
+// chunk's.  After each chunk `after_chunk(c0, cn, chunk_stream)` is called (c0 relative to q0) with the
+// chunk's kernels enqueued on chunk_stream: the host-buffer API starts that chunk's result D2H there.
+// On return the caller's stream has been made to wait for everything enqueued on the second stream.
 template <typename F>
 int stage_svd(tq_ctx *ctx, int64_t q0, int64_t n, bool debug, const OutPtrs &out, hipStream_t stream, F &&after_chunk)
 {
@@ -574,28 +592,40 @@ int stage_svd(tq_ctx *ctx, int64_t q0, int64_t n, bool debug, const OutPtrs &out
         return fail(ctx, TQ_ERR_INVALID_ARG, "rows [%lld,+%lld) are outside the scanned batch of %lld quartets",
                     (long long)q0, (long long)n, (long long)ctx->scanned_Q);
     const int64_t chunk = ctx->svd_chunk < n ? ctx->svd_chunk : n;
-    int rc = ctx->svd_method == 1 ? ensure_svd(ctx, chunk) : TQ_OK;
+    int rc = ensure_svd(ctx, chunk);
     if (rc) return rc;
-    for (int64_t c0 = 0; c0 < n; c0 += chunk) {
+    const bool two = ctx->svd_streams > 1 && n > chunk;
+    if (two) {
+        TQ_HIP(ctx, hipEventRecord(ctx->evFork, stream));
+        TQ_HIP(ctx, hipStreamWaitEvent(ctx->sX, ctx->evFork, 0));
+    }
+    int64_t ci = 0;
+    for (int64_t c0 = 0; c0 < n; c0 += chunk, ++ci) {
         const int64_t cn = (n - c0) < chunk ? (n - c0) : chunk;
+        const int lane = two ? (int)(ci & 1) : 0;
+        hipStream_t st = lane ? ctx->sX : stream;
         if (ctx->phases & 2) {
             const uint32_t *cm = ctx->d_cm + (size_t)(q0 + c0) * 256;
             const uint32_t *dq = ctx->scanned_q + (q0 + c0) * 4;
             const OutPtrs o = offset_out(out, c0);
-            if ((rc = mark(ctx, TAG_ORIGIN, stream))) return rc;
+            if ((rc = mark(ctx, TAG_ORIGIN, st, lane))) break;
             if (ctx->svd_method == 0)
-                rc = debug ? launch_svd<true>(ctx, cm, dq, cn, o, stream) : launch_svd<false>(ctx, cm, dq, cn, o, stream);
+                rc = debug ? launch_svd<true>(ctx, cm, dq, cn, o, st, lane) : launch_svd<false>(ctx, cm, dq, cn, o, st, lane);
             else
-                rc = debug ? launch_hqr<true>(ctx, cm, dq, cn, o, stream) : launch_hqr<false>(ctx, cm, dq, cn, o, stream);
-            if (rc) return rc;
+                rc = debug ? launch_hqr<true>(ctx, cm, dq, cn, o, st, lane) : launch_hqr<false>(ctx, cm, dq, cn, o, st, lane);
+            if (rc) break;
         }
-        if ((rc = after_chunk(c0, cn))) return rc;
+        if ((rc = after_chunk(c0, cn, st))) break;
     }
-    return TQ_OK;
+    if (two) {                                   // join, also on the error path: nothing may stay forked
+        if (hipEventRecord(ctx->evJoin, ctx->sX) != hipSuccess || hipStreamWaitEvent(stream, ctx->evJoin, 0) != hipSuccess)
+            if (!rc) rc = fail(ctx, TQ_ERR_HIP, "stream join failed");
+    }
+    return rc;
 }
 
 struct NoChunkHook {
-    int operator()(int64_t, int64_t) const { return TQ_OK; }
+    int operator()(int64_t, int64_t, hipStream_t) const { return TQ_OK; }
 };
 
 // One pass of the path over quartets dq[0..Q) with device outputs: scan batches of <= ctx->batch quartets,
@@ -614,7 +644,7 @@ int launch(tq_ctx *ctx, const uint32_t *dq, int64_t Q, int subsample, bool debug
         rc = stage_scan(ctx, dq + q0 * 4, n, subsample, input_sorted, stream);
         if (rc) return rc;
         rc = stage_svd(ctx, 0, n, debug, offset_out(out, q0), stream,
-                       [&](int64_t c0, int64_t cn) { return after_chunk(q0 + c0, cn); });
+                       [&](int64_t c0, int64_t cn, hipStream_t st) { return after_chunk(q0 + c0, cn, st); });
         if (rc) return rc;
     }
     ctx->scanned_Q = 0;          // the slab belongs to this call only
@@ -669,8 +699,9 @@ struct HostSink {
 
     int begin(int64_t Q)
     {
-        direct = is_pinned(rstat, (size_t)Q * 8) && is_pinned(rscor, (size_t)Q * 24) &&
-                 (!flags || is_pinned(flags, (size_t)Q));
+        // (a call whose results fit one small piece is cheaper as ONE staged copy than as three direct ones)
+        direct = (size_t)Q * 33 > ((size_t)1 << 20) && is_pinned(rstat, (size_t)Q * 8) &&
+                 is_pinned(rscor, (size_t)Q * 24) && (!flags || is_pinned(flags, (size_t)Q));
         if (!direct) {
             stage_rows = ctx->svd_chunk < Q ? ctx->svd_chunk : Q;
             // small calls (the reference's distributor hands out chunks of a few thousand quartets,
@@ -699,14 +730,14 @@ struct HostSink {
         if (flags) memcpy(flags + p.q0, s + off_flags, (size_t)p.n);
         return TQ_OK;
     }
-    // chunk [q0, q0+n) has been enqueued on sK
-    int chunk(int64_t q0, int64_t n)
+    // the kernels of chunk [q0, q0+n) have been enqueued on `st`
+    int chunk(int64_t q0, int64_t n, hipStream_t st)
     {
         hipEvent_t ready, done;
         int rc = pipe_event(ctx, 2 * (nchunk % 4), &ready);
         if (!rc) rc = pipe_event(ctx, 2 * (nchunk % 4) + 1, &done);
         if (rc) return rc;
-        TQ_HIP(ctx, hipEventRecord(ready, ctx->sK));
+        TQ_HIP(ctx, hipEventRecord(ready, st));
         TQ_HIP(ctx, hipStreamWaitEvent(ctx->sC, ready, 0));
         if (direct) {
             TQ_HIP(ctx, hipMemcpyAsync(rstat + q0 * 2, dev->rstat + q0 * 2, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->sC));
@@ -765,7 +796,7 @@ int resolve_to_host(tq_ctx *ctx, const uint32_t *dq, int64_t Q, int subsample, b
     int rc = sink.begin(Q);
     if (rc) return rc;
     rc = launch(ctx, dq, Q, subsample, false, input_sorted, out, ctx->sK,
-                [&](int64_t q0, int64_t n) { return sink.chunk(q0, n); });
+                [&](int64_t q0, int64_t n, hipStream_t st) { return sink.chunk(q0, n, st); });
     if (rc) return rc;
     return sink.finish();
 }
@@ -813,6 +844,11 @@ void tq_destroy(tq_ctx *ctx)
     if (ctx->d_nsnps) (void)hipFree(ctx->d_nsnps);
     if (ctx->sK) (void)hipStreamDestroy(ctx->sK);
     if (ctx->sC) (void)hipStreamDestroy(ctx->sC);
+    if (ctx->sX) {
+        (void)hipStreamDestroy(ctx->sX);
+        (void)hipEventDestroy(ctx->evFork);
+        (void)hipEventDestroy(ctx->evJoin);
+    }
     for (auto e : ctx->pipe_events) (void)hipEventDestroy(e);
     for (auto &m : ctx->marks) (void)hipEventDestroy(m.ev);
     for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
@@ -1086,15 +1122,15 @@ int tq_timing_read_kernels(tq_ctx *ctx, double *ms, int n_ms, int64_t *calls)
 {
     if (!ctx || (n_ms > 0 && !ms)) return TQ_ERR_INVALID_ARG;
     double t[TAG_COUNT] = {0, 0, 0, 0, 0};
-    hipEvent_t prev = nullptr;
+    hipEvent_t prev[2] = {nullptr, nullptr};
     int rc = TQ_OK;
     for (auto &m : ctx->marks) {
         if (!rc && hipEventSynchronize(m.ev) != hipSuccess) rc = fail(ctx, TQ_ERR_HIP, "timing event failed");
-        if (!rc && m.tag >= 0 && m.tag < TAG_COUNT && prev) {
+        if (!rc && m.tag >= 0 && m.tag < TAG_COUNT && prev[m.lane]) {
             float a = 0.f;
-            if (hipEventElapsedTime(&a, prev, m.ev) == hipSuccess) t[m.tag] += a;
+            if (hipEventElapsedTime(&a, prev[m.lane], m.ev) == hipSuccess) t[m.tag] += a;
         }
-        prev = m.ev;
+        prev[m.lane] = m.ev;
         ctx->event_pool.push_back(m.ev);
     }
     ctx->marks.clear();
@@ -1146,7 +1182,12 @@ int tq_set_option(tq_ctx *ctx, const char *name, int64_t value)
     }
     if (!strcmp(name, "svd_chunk")) {
         if (value < 0) return fail(ctx, TQ_ERR_INVALID_ARG, "svd_chunk must be >= 0");
-        ctx->svd_chunk = value ? value : (1 << 17);
+        ctx->svd_chunk = value ? value : (1 << 18);
+        return TQ_OK;
+    }
+    if (!strcmp(name, "svd_streams")) {
+        if (value < 0 || value > 2) return fail(ctx, TQ_ERR_INVALID_ARG, "svd_streams must be 0 (default), 1 or 2");
+        ctx->svd_streams = value ? (int)value : 2;
         return TQ_OK;
     }
     if (!strcmp(name, "bdsqr_maxit")) {

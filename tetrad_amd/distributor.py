@@ -5,13 +5,19 @@ Replaces the reference's ipyparallel load-balanced dispatch
 MI355X-native scheme of SURVEY.md section 8e:
 
   * one process per GPU (torch.distributed; backend "nccl" is RCCL over xGMI),
-  * the global quartet index space [0,Q) is cut into `world` contiguous ranges, balanced +-1;
-    the genotype matrix is replicated (<= 26 MB), so there is no scatter,
-  * every rank resolves its range with the HIP engine and ONE all-gather of fixed-size
-    32-byte records per quartet (3 x f64 score bit patterns + packed {topology, flags, nsnps}, moved as int64) returns
-    the whole batch, in global-index order, to every rank (rank 0 feeds QMC).
+  * the genotype matrix is replicated (<= 26 MB), so there is no scatter; the quartets of one
+    replicate are cut into a few large PIECES (contiguous ranges of the global index space), each
+    piece into `world` contiguous per-rank parts, balanced +-1,
+  * every rank scans ALL its parts in one pass (one ordering + one site-scan launch), then runs the
+    singular-value stage piece by piece; as soon as a piece is done its fixed-size slab
+    `[rstat u32[p,2] | rscor f64[p,3] | flags u8[p]]` (33 bytes per quartet) goes into ONE all-gather
+    per piece, the gathered parts are regrouped into global order on the device and copied to the
+    destination rank's host arrays -- all of that under the kernels of the next piece.  A replicate
+    of up to ~3e5 quartets per rank is a single piece = one collective per replicate; large batches
+    use up to 8 pieces of >= 32k quartets per rank so that only the last piece's gather + D2H is
+    exposed.
 
-The per-rank compute step is injectable so that the sharding / padding / gather logic is
+The per-rank compute step is injectable so that the partition / gather / regroup logic is
 covered by world_size-2 `gloo` tests on CPU; the default is the GPU engine and there is no
 CPU fallback in this module.
 """
@@ -22,7 +28,8 @@ from typing import Callable, Iterable, Optional
 
 import numpy as np
 
-RECORD_WORDS = 4        # 3 score bit patterns + 1 packed word (int64 each) -> 32 bytes per quartet
+MIN_PART_ROWS = 32768          # a rank's part of a piece is at least this many quartets (keeps the GPU filled)
+MAX_PIECES = 8
 
 
 def shard_bounds(Q: int, world: int) -> list[tuple[int, int]]:
@@ -52,30 +59,43 @@ def get_chunksize(nquartets: int, ncores: int) -> int:
     return max(1, chunk + extra)
 
 
-def pack_records(rstat: np.ndarray, rscor: np.ndarray, flags: np.ndarray) -> np.ndarray:
-    """(rstat u32[n,2], rscor f64[n,3], flags u8[n]) -> int64[n,4] records (scores as raw bits)."""
-    n = rstat.shape[0]
-    rec = np.empty((n, RECORD_WORDS), dtype=np.int64)
-    rec[:, :3] = np.ascontiguousarray(rscor, dtype=np.float64).view(np.int64)
-    word = (rstat[:, 0].astype(np.uint64) & np.uint64(0xFF)) | (flags.astype(np.uint64) << np.uint64(8)) \
-        | (rstat[:, 1].astype(np.uint64) << np.uint64(32))
-    rec[:, 3] = word.view(np.int64)
-    return rec
+class ShardPlan:
+    """Partition of the global index space [0,Q): `npieces` contiguous pieces, piece i = [start[i], end[i]),
+    cut into `world` contiguous parts of `part[i]` = ceil(len/world) rows (the last parts may be short or
+    empty).  The gathered slab of piece i holds world*part[i] >= len rows in global order; the surplus
+    rows land beyond end[i] and are overwritten by piece i+1 (or fall into the `world` slack rows at the
+    end of the destination arrays)."""
 
+    def __init__(self, Q: int, world: int, pieces: Optional[int] = None):
+        self.Q, self.world = int(Q), int(world)
+        if pieces is None:
+            pieces = self.Q // (self.world * MIN_PART_ROWS)
+        self.npieces = int(max(1, min(MAX_PIECES, pieces, max(1, self.Q))))
+        b = shard_bounds(self.Q, self.npieces)
+        self.start = [lo for lo, _ in b]
+        self.end = [hi for _, hi in b]
+        self.part = [max(1, -(-(hi - lo) // self.world)) for lo, hi in b]
+        self.rows_padded = self.Q + self.world            # destination arrays: Q rows + slack
 
-def unpack_records(rec: np.ndarray):
-    """Inverse of pack_records."""
-    rec = np.ascontiguousarray(rec, dtype=np.int64)
-    word = rec[:, 3].copy().view(np.uint64)
-    rstat = np.empty((rec.shape[0], 2), dtype=np.uint32)
-    rstat[:, 0] = (word & np.uint64(0xFF)).astype(np.uint32)
-    rstat[:, 1] = (word >> np.uint64(32)).astype(np.uint32)
-    flags = ((word >> np.uint64(8)) & np.uint64(0xFF)).astype(np.uint8)
-    return rstat, np.ascontiguousarray(rec[:, :3]).view(np.float64), flags
+    def part_range(self, i: int, rank: int) -> tuple[int, int]:
+        lo = min(self.start[i] + rank * self.part[i], self.end[i])
+        hi = min(lo + self.part[i], self.end[i])
+        return lo, hi
+
+    def local_ranges(self, rank: int) -> list[tuple[int, int]]:
+        return [self.part_range(i, rank) for i in range(self.npieces)]
+
+    def local_index(self, rank: int) -> np.ndarray:
+        """Global row numbers of the rank's quartets, in the order the rank processes them."""
+        r = self.local_ranges(rank)
+        return np.concatenate([np.arange(lo, hi, dtype=np.int64) for lo, hi in r]) if r else np.zeros(0, np.int64)
+
+    def slab_bytes(self, i: int) -> int:
+        return (33 * self.part[i] + 15) // 16 * 16
 
 
 def gpu_compute(device_id: int) -> Callable:
-    """Default per-rank compute: the HIP engine on `device_id` (data uploaded once per replicate)."""
+    """Single-rank compute through the host-buffer API of the HIP engine on `device_id`."""
     from .resolve_quartets import _ensure_resident, get_engine
 
     def run(tmparr, tmpmap, quartets, subsample_snps):
@@ -86,88 +106,238 @@ def gpu_compute(device_id: int) -> Callable:
     return run
 
 
+class ShardedResolver:
+    """Buffers and control flow of the multi-GPU path for batches of Q quartets (module docstring).
+
+    engine   a QuartetEngine with the replicate resident (device path), or None with `compute` given
+    compute  injected per-rank compute `(quartets_local, subsample) -> (rstat, rscor, flags)` on host arrays
+             (CPU tests of the partition / gather / regroup logic)
+    dst      rank that receives the host arrays (None: every rank)
+    nbuf     independent buffer sets: `start(b=k)` / `finish(b=k)` of different sets may be in flight together
+    """
+
+    def __init__(self, Q: int, *, engine=None, compute: Optional[Callable] = None, group=None, device=None,
+                 pieces: Optional[int] = None, dst: Optional[int] = None, nbuf: int = 1):
+        import torch
+        import torch.distributed as dist
+        if (engine is None) == (compute is None):
+            raise ValueError("give either `engine` (device path) or `compute` (injected host compute)")
+        self.torch, self.dist, self.group = torch, dist, group
+        if dist.is_available() and dist.is_initialized():
+            self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
+            self.backend = dist.get_backend(group)
+        else:
+            self.world, self.rank, self.backend = 1, 0, None
+        self.engine, self.compute, self.dst = engine, compute, dst
+        self.plan = ShardPlan(Q, self.world, pieces)
+        self.Q = int(Q)
+        self.ranges = self.plan.local_ranges(self.rank)
+        self.offsets = np.concatenate([[0], np.cumsum([hi - lo for lo, hi in self.ranges])]).astype(np.int64)
+        self.n_local = int(self.offsets[-1])
+        if engine is not None:
+            idx = engine.device_id if device is None else torch.device(device).index
+            self.dev = torch.device("cuda", idx)
+        else:
+            self.dev = torch.device("cpu")
+        # where the collective runs: on the GPUs with RCCL, on the host with gloo
+        self.gdev = self.dev if (self.backend == "nccl" or self.world == 1) else torch.device("cpu")
+        self.on_gpu = self.gdev.type == "cuda"
+        P = self.plan
+        self.sets = []
+        for _ in range(nbuf):
+            s = dict(
+                slabs=[torch.zeros(P.slab_bytes(i), dtype=torch.uint8, device=self.dev) for i in range(P.npieces)],
+                gathered=[torch.zeros(self.world * P.slab_bytes(i), dtype=torch.uint8, device=self.gdev)
+                          if self.world > 1 else None for i in range(P.npieces)],
+                # the whole batch in global order (every rank holds it after the gathers)
+                all_rstat=torch.zeros(P.rows_padded * 8, dtype=torch.uint8, device=self.gdev),
+                all_rscor=torch.zeros(P.rows_padded * 24, dtype=torch.uint8, device=self.gdev),
+                all_flags=torch.zeros(P.rows_padded, dtype=torch.uint8, device=self.gdev),
+                host=None, done=None, works=[])
+            self.sets.append(s)
+        self.side = torch.cuda.Stream(self.dev) if self.on_gpu else None
+        self.d_q = None
+        self.q_local = None
+
+    # -- input ---------------------------------------------------------------------------------
+    def set_quartets(self, quartets: np.ndarray):
+        """`quartets` u32[Q,4], identical on every rank; the rank keeps (and uploads) its own rows."""
+        quartets = np.asarray(quartets).reshape(-1, 4)
+        if quartets.shape[0] != self.Q:
+            raise ValueError(f"resolver was built for {self.Q} quartets, got {quartets.shape[0]}")
+        parts = [quartets[lo:hi] for lo, hi in self.ranges]
+        self.q_local = np.ascontiguousarray(np.concatenate(parts, axis=0), dtype=np.uint32)
+        if self.engine is not None:
+            self.d_q = self.torch.from_numpy(self.q_local.view(np.int32)).to(self.dev)
+
+    def set_ranks(self, ranks: np.ndarray):
+        """Lexicographic ranks (combinations.py:94-114) of the Q sampled quartets, identical on every rank:
+        the rank uploads its own 8 bytes per quartet and unranks them on the device."""
+        if self.engine is None:
+            raise ValueError("set_ranks needs the device path")
+        torch = self.torch
+        ranks = np.asarray(ranks)
+        if ranks.shape[0] != self.Q:
+            raise ValueError(f"resolver was built for {self.Q} quartets, got {ranks.shape[0]}")
+        local = np.ascontiguousarray(np.concatenate([ranks[lo:hi] for lo, hi in self.ranges]), dtype=np.int64)
+        d_r = torch.from_numpy(local).to(self.dev)
+        self.d_q = torch.empty((max(1, self.n_local), 4), dtype=torch.int32, device=self.dev)
+        if self.n_local:
+            self.engine.unrank_dev(d_r.data_ptr(), self.n_local, self.d_q.data_ptr(),
+                                   torch.cuda.current_stream(self.dev).cuda_stream)
+        self.q_local = None
+
+    # -- one batch -------------------------------------------------------------------------------
+    def _wants_host(self) -> bool:
+        return self.dst is None or self.dst == self.rank
+
+    def start(self, subsample_snps: bool = True, b: int = 0):
+        """Enqueue one pass over the batch (kernels, gathers, regrouping, D2H); returns without waiting."""
+        torch, dist, P = self.torch, self.dist, self.plan
+        s = self.sets[b]
+        if s["done"] is not None or s["works"]:
+            raise RuntimeError("buffer set still in flight: call finish() first")
+        want_host = self._wants_host()
+        if want_host:
+            if self.on_gpu:
+                from .engine import pinned_empty
+                host = (pinned_empty(P.rows_padded * 8, np.uint8), pinned_empty(P.rows_padded * 24, np.uint8),
+                        pinned_empty(P.rows_padded, np.uint8))
+            else:
+                host = (s["all_rstat"].numpy(), s["all_rscor"].numpy(), s["all_flags"].numpy())
+            s["host"] = host
+            h_t = [torch.from_numpy(h) for h in host] if self.on_gpu else None
+        if self.engine is not None:
+            cur = torch.cuda.current_stream(self.dev)
+            if self.n_local:
+                self.engine.scan_dev(self.d_q.data_ptr(), self.n_local, subsample_snps, cur.cuda_stream)
+        else:
+            rstat, rscor, flags = self.compute(self.q_local, subsample_snps) if self.n_local else (
+                np.zeros((0, 2), np.uint32), np.zeros((0, 3), np.float64), np.zeros(0, np.uint8))
+        for i in range(P.npieces):
+            p, blk = P.part[i], P.slab_bytes(i)
+            lo, hi = self.ranges[i]
+            n, off = hi - lo, int(self.offsets[i])
+            slab = s["slabs"][i]
+            if self.engine is not None:
+                if n:
+                    base = slab.data_ptr()
+                    self.engine.svd_dev(off, n, base, base + 8 * p, base + 32 * p, cur.cuda_stream)
+            else:
+                sl = slab.numpy()
+                sl[:8 * n] = np.ascontiguousarray(rstat[off:off + n], dtype=np.uint32).view(np.uint8).ravel()
+                sl[8 * p:8 * p + 24 * n] = np.ascontiguousarray(rscor[off:off + n], dtype=np.float64).view(np.uint8).ravel()
+                sl[32 * p:32 * p + n] = np.asarray(flags[off:off + n], dtype=np.uint8)
+            # ONE collective per piece: every rank receives the parts of all ranks
+            work = None
+            if self.world > 1:
+                src = slab if slab.device == self.gdev else slab.cpu()        # gloo rehearsal with the engine
+                work = dist.all_gather_into_tensor(s["gathered"][i], src, group=self.group, async_op=True)
+                g = s["gathered"][i].view(self.world, blk)
+            else:
+                g = slab.view(1, blk)
+            rows = self.world * p
+            r0 = P.start[i]
+
+            def regroup_and_copy(g=g, p=p, rows=rows, r0=r0, work=work):
+                if work is not None:
+                    work.wait()                 # nccl: the current (side) stream waits; gloo: the host waits
+                s["all_rstat"][8 * r0:8 * (r0 + rows)].view(self.world, 8 * p).copy_(g[:, :8 * p])
+                s["all_rscor"][24 * r0:24 * (r0 + rows)].view(self.world, 24 * p).copy_(g[:, 8 * p:32 * p])
+                s["all_flags"][r0:r0 + rows].view(self.world, p).copy_(g[:, 32 * p:33 * p])
+                if want_host and self.on_gpu:
+                    h_t[0][8 * r0:8 * (r0 + rows)].copy_(s["all_rstat"][8 * r0:8 * (r0 + rows)], non_blocking=True)
+                    h_t[1][24 * r0:24 * (r0 + rows)].copy_(s["all_rscor"][24 * r0:24 * (r0 + rows)], non_blocking=True)
+                    h_t[2][r0:r0 + rows].copy_(s["all_flags"][r0:r0 + rows], non_blocking=True)
+
+            if self.on_gpu:
+                if work is None:
+                    self.side.wait_stream(cur)                 # the piece's kernels
+                with torch.cuda.stream(self.side):
+                    regroup_and_copy()
+            else:
+                if self.engine is not None and self.world == 1:
+                    torch.cuda.synchronize(self.dev)
+                regroup_and_copy()
+        if self.on_gpu:
+            ev = torch.cuda.Event()
+            ev.record(self.side)
+            s["done"] = ev
+        else:
+            s["done"] = True
+
+    def finish(self, b: int = 0):
+        """Wait for set `b`; returns (rstat u32[Q,2], rscor f64[Q,3], flags u8[Q]) host arrays on the
+        destination rank(s), (None, None, None) elsewhere."""
+        s = self.sets[b]
+        if s["done"] is None:
+            raise RuntimeError("nothing in flight: call start() first")
+        if self.on_gpu:
+            s["done"].synchronize()
+        s["done"] = None
+        host, s["host"] = s["host"], None
+        if host is None:
+            return None, None, None
+        Q = self.Q
+        rstat = host[0][:8 * Q].view(np.uint32).reshape(Q, 2)
+        rscor = host[1][:24 * Q].view(np.float64).reshape(Q, 3)
+        flags = host[2][:Q]
+        if not self.on_gpu:                                     # the all_* buffers are re-used by the next batch
+            rstat, rscor, flags = rstat.copy(), rscor.copy(), flags.copy()
+        return rstat, rscor, flags
+
+    def resolve(self, subsample_snps: bool = True):
+        self.start(subsample_snps)
+        return self.finish()
+
+    def device_rows(self, b: int = 0):
+        """The gathered batch in global order as it sits on this rank's gather device (valid after finish):
+        (rstat int32[Q,2], rscor f64[Q,3], flags u8[Q]) torch views."""
+        s, Q, torch = self.sets[b], self.Q, self.torch
+        return (s["all_rstat"][:8 * Q].view(torch.int32).view(Q, 2), s["all_rscor"][:24 * Q].view(torch.float64).view(Q, 3),
+                s["all_flags"][:Q])
+
+
+_resolvers: dict = {}
+
+
 def resolve_sharded(tmparr, tmpmap, quartets, subsample_snps: bool = True, *, group=None,
-                    compute: Optional[Callable] = None, device=None):
+                    compute: Optional[Callable] = None, device=None, dst: Optional[int] = None,
+                    pieces: Optional[int] = None):
     """Resolve `quartets` (u32[Q,4], identical on every rank) across the ranks of `group`.
 
-    Returns (quartets, rstat u32[Q,2], rscor f64[Q,3], flags u8[Q]) on every rank, rows in the
-    order of `quartets`.  With an uninitialised process group this is the 1-GPU path."""
+    Returns (quartets, rstat u32[Q,2], rscor f64[Q,3], flags u8[Q]), rows in the order of `quartets`,
+    on every rank (`dst=None`) or on rank `dst` only (the other ranks get None for the three arrays: the
+    reference's distributor consumes the rows on the client alone, run_inference.py:232-244).  With an
+    uninitialised process group this is the 1-GPU path.  `compute(tmparr, tmpmap, quartets, subsample)`
+    replaces the HIP engine in CPU tests of the control flow."""
     import torch
     import torch.distributed as dist
 
     quartets = np.ascontiguousarray(quartets, dtype=np.uint32).reshape(-1, 4)
     Q = quartets.shape[0]
-    if dist.is_available() and dist.is_initialized():
-        world, rank = dist.get_world_size(group), dist.get_rank(group)
-        backend = dist.get_backend(group)
-    else:
-        world, rank, backend = 1, 0, None
-    lo, hi = shard_bounds(Q, world)[rank]
-    if compute is None and world > 1:
-        return _resolve_sharded_device(tmparr, tmpmap, quartets, subsample_snps, group, world, rank, backend,
-                                       lo, hi, device)
-    if compute is None:
+    world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
+    if world == 1 and compute is None:
         dev_id = torch.cuda.current_device() if device is None else torch.device(device).index
-        compute = gpu_compute(dev_id)
-    rstat, rscor, flags = compute(tmparr, tmpmap, quartets[lo:hi], subsample_snps)
-    if world == 1:
+        rstat, rscor, flags = gpu_compute(dev_id)(tmparr, tmpmap, quartets, subsample_snps)
         return quartets, rstat, rscor, flags
-    # fixed-size slabs: pad every rank's records to ceil(Q/world) rows
-    slab = -(-Q // world)
-    rec = np.zeros((slab, RECORD_WORDS), dtype=np.int64)
-    rec[:hi - lo] = pack_records(rstat, rscor, flags)
-    tdev = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
-    local = torch.from_numpy(rec).to(tdev)
-    gathered = torch.empty((world * slab, RECORD_WORDS), dtype=torch.int64, device=tdev)
-    dist.all_gather_into_tensor(gathered, local, group=group)
-    g = gathered.cpu().numpy().reshape(world, slab, RECORD_WORDS)
-    parts = [g[r, :b - a] for r, (a, b) in enumerate(shard_bounds(Q, world))]
-    rstat, rscor, flags = unpack_records(np.concatenate(parts, axis=0))
-    return quartets, rstat, rscor, flags
-
-
-def _resolve_sharded_device(tmparr, tmpmap, quartets, subsample_snps, group, world, rank, backend, lo, hi, device):
-    """The N>1 path with the HIP engine: the rank's rows never visit the host before the gather.  The
-    engine writes `[rstat u32[slab,2] | rscor f64[slab,3] | flags u8[slab]]` into ONE device slab
-    (33 bytes per quartet, padded to ceil(Q/world) rows), one all-gather (RCCL over xGMI with the
-    "nccl" backend) collects the slabs of all ranks, one D2H brings them to the host."""
-    import torch
-    import torch.distributed as dist
-    from .resolve_quartets import _ensure_resident, get_engine
-
-    Q = quartets.shape[0]
-    dev_id = torch.cuda.current_device() if device is None else torch.device(device).index
-    dev = torch.device("cuda", dev_id)
-    eng = get_engine(dev_id)
-    _ensure_resident(eng, tmparr, tmpmap)
-    slab = -(-Q // world)
-    n = hi - lo
-    blk = (33 * slab + 7) // 8 * 8                   # bytes per rank, 8-byte aligned
-    local = torch.zeros(blk, dtype=torch.uint8, device=dev)
-    if n:
-        d_q = torch.from_numpy(quartets[lo:hi].astype(np.int32)).to(dev)
-        stream = torch.cuda.current_stream(dev).cuda_stream
-        eng.resolve_dev(d_q.data_ptr(), n, subsample_snps, local.data_ptr(), local.data_ptr() + 8 * slab,
-                        local.data_ptr() + 32 * slab, stream)
-    if backend == "nccl":
-        gathered = torch.empty(world * blk, dtype=torch.uint8, device=dev)
-        dist.all_gather_into_tensor(gathered, local, group=group)
-        g = gathered.cpu().numpy()
-    else:                                           # gloo rehearsal: the collective runs on host tensors
-        torch.cuda.synchronize(dev)
-        loc = local.cpu()
-        gathered = torch.empty(world * blk, dtype=torch.uint8)
-        dist.all_gather_into_tensor(gathered, loc, group=group)
-        g = gathered.numpy()
-    g = g.reshape(world, blk)
-    rstat = np.empty((Q, 2), dtype=np.uint32)
-    rscor = np.empty((Q, 3), dtype=np.float64)
-    flags = np.empty(Q, dtype=np.uint8)
-    for r, (a, b) in enumerate(shard_bounds(Q, world)):
-        m = b - a
-        rstat[a:b] = g[r, :8 * slab].view(np.uint32).reshape(slab, 2)[:m]
-        rscor[a:b] = g[r, 8 * slab:32 * slab].view(np.float64).reshape(slab, 3)[:m]
-        flags[a:b] = g[r, 32 * slab:33 * slab][:m]
+    if Q == 0:
+        return quartets, np.zeros((0, 2), np.uint32), np.zeros((0, 3), np.float64), np.zeros(0, np.uint8)
+    if compute is not None:
+        res = ShardedResolver(Q, compute=lambda q, sub: compute(tmparr, tmpmap, q, sub), group=group, dst=dst,
+                              pieces=pieces)
+    else:
+        from .resolve_quartets import _ensure_resident, get_engine
+        dev_id = torch.cuda.current_device() if device is None else torch.device(device).index
+        eng = get_engine(dev_id)
+        _ensure_resident(eng, tmparr, tmpmap)
+        key = (Q, world, dev_id, dst, pieces, id(group))
+        res = _resolvers.get("res") if _resolvers.get("key") == key else None
+        if res is None:                                  # buffers are kept for the next batch of this size
+            res = ShardedResolver(Q, engine=eng, group=group, device=dev_id, dst=dst, pieces=pieces)
+            _resolvers.update(key=key, res=res)
+    res.set_quartets(quartets)
+    rstat, rscor, flags = res.resolve(subsample_snps)
     return quartets, rstat, rscor, flags
 
 
@@ -207,11 +377,18 @@ def format_tsv(rqrts: np.ndarray, rscor: np.ndarray, rstat: np.ndarray) -> str:
     return format_tsv_bytes(rqrts, rscor, rstat).decode("ascii")
 
 
+GATHER_ROWS = 1 << 23          # quartets resolved (and gathered) per collective round of `distributor`
+
+
 def distributor(database_file: Path, qrts_file: Path, nsamples: int, qiter: Iterable, subsample_snps: bool,
-                client=None, *, group=None, compute: Optional[Callable] = None) -> Path:
-    """Mirror of run_inference.py:184-251: resolve every chunk of `qiter` and append the rows
-    to `qrts_file`.  `client` (an ipyparallel Client in the reference) is accepted and ignored:
-    the GPUs of the node take its place.  Only rank 0 writes the file."""
+                client=None, *, group=None, compute: Optional[Callable] = None,
+                gather_rows: int = GATHER_ROWS) -> Path:
+    """Mirror of run_inference.py:184-251: resolve every chunk of `qiter` and write the rows to
+    `qrts_file`.  `client` (an ipyparallel Client in the reference) is accepted and ignored: the GPUs of
+    the node take its place.  The reference hands chunk after chunk to whichever engine is free; here the
+    chunks of one replicate are collected (up to `gather_rows` quartets: every replicate the reference's
+    own size limits allow in practice) and resolved as ONE sharded batch -- one scan launch per rank, one
+    all-gather per piece -- and only rank 0 receives the rows and writes the file."""
     import torch.distributed as dist
     from .resolve_quartets import load_database
 
@@ -220,11 +397,25 @@ def distributor(database_file: Path, qrts_file: Path, nsamples: int, qiter: Iter
     if rank == 0:
         qrts_file.write_text("")                                   # :209
     tmparr, tmpmap = load_database(database_file)
-    for chunk in qiter:                                            # :216-223
-        qrts = np.array(list(chunk), dtype=np.uint32).reshape(-1, 4)
+
+    def flush(parts):
+        qrts = parts[0] if len(parts) == 1 else np.concatenate(parts, axis=0)
         rqrts, rstat, rscor, _ = resolve_sharded(tmparr, tmpmap, qrts, subsample_snps, group=group,
-                                                 compute=compute)
+                                                 compute=compute, dst=0)
         if rank == 0:
             with open(qrts_file, "ab") as out:                     # :240-244
                 out.write(format_tsv_bytes(rqrts, rscor, rstat))
+
+    parts, nrows = [], 0
+    for chunk in qiter:                                            # :216-223
+        qrts = np.array(list(chunk), dtype=np.uint32).reshape(-1, 4)
+        if qrts.shape[0] == 0:
+            continue
+        parts.append(qrts)
+        nrows += qrts.shape[0]
+        if nrows >= gather_rows:
+            flush(parts)
+            parts, nrows = [], 0
+    if parts:
+        flush(parts)
     return qrts_file

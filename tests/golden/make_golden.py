@@ -160,10 +160,10 @@ def main():
     arr, tmap, qrts = synth.make_config("c1")
     save("c1_T16_S5000", arr, tmap, qrts, ref, with_cmats=False)
 
-    # (10) slices of c2 / c3 shaped inputs are regenerated from the seed on the fly by
+    # (10) slices of c2 / c3 / c4 shaped inputs are regenerated from the seed on the fly by
     #      the tests (inputs are deterministic); only the reference outputs for a few
     #      quartets are stored here.
-    for cfg, nq in (("c2", 24), ("c3", 12)):
+    for cfg, nq in (("c2", 24), ("c3", 12), ("c4", 12)):
         T, S, _ = synth.CONFIGS[cfg]
         arr, tmap = synth.simulate_tmparr(T, S, synth.CONFIG_SEEDS[cfg])
         qrts = synth.random_quartets(T, nq, seed=777)
@@ -214,6 +214,47 @@ def make_resample_golden():
     np.savez_compressed(OUT / "spans_toy.npz", maparr=toy, spans=ref.jit_get_spans(toy))
 
 
+def make_c5_golden():
+    """BASELINE.json configs[4] shape: ONE bootstrap replicate of the c5 source made by the REFERENCE's
+    resampler (jit_resample + jit_resolve_ambigs run under NumPy's legacy RNG, draws on the project
+    Generator in the order of run_inference.py:117-123, recode as :133-136), then the reference worker on
+    a few quartets of it.  The replicate itself (6.4 MB) is not stored: tests rebuild it with
+    oracle/resample.py, which is pinned bit-for-bit against the same reference code, and check its CRC."""
+    import zlib
+    refj = load_reference_jitted()
+    ref = load_reference()
+    seqarr, maparr, spans = synth.make_c5_source()
+    rng = np.random.default_rng(synth.CONFIG_SEEDS["c5"])
+    nloci = spans.shape[0]
+    assert np.array_equal(refj.jit_get_spans(maparr.astype(np.int64)), spans)
+    lidxs = rng.choice(nloci, nloci, replace=True)                       # run_inference.py:117
+    seed1 = int(rng.integers(2**31))
+    tmparr, tmpmap = refj.jit_resample(seqarr, spans, lidxs, seed=seed1)  # :120
+    seed2 = int(rng.integers(2**31))
+    tmparr = refj.jit_resolve_ambigs(tmparr, seed=seed2)                  # :123
+    tmparr[tmparr == 65] = 0                                              # :133-136
+    tmparr[tmparr == 67] = 1
+    tmparr[tmparr == 71] = 2
+    tmparr[tmparr == 84] = 3
+    qrts = synth.random_quartets(seqarr.shape[0], 12, seed=778)
+    blob = dict(quartets=qrts, lidxs=lidxs, seed_resample=np.array(seed1), seed_ambig=np.array(seed2),
+                replicate_shape=np.array(tmparr.shape), replicate_crc32=np.array(zlib.crc32(tmparr.tobytes())),
+                tmpmap_crc32=np.array(zlib.crc32(np.ascontiguousarray(tmpmap).tobytes())),
+                numpy_version=np.array(np.__version__))
+    for sub in (False, True):
+        res = run_reference(ref, tmparr, tmpmap, qrts, sub, with_cmats=True)
+        tag = "sub" if sub else "full"
+        for k, v in res.items():
+            blob[f"{tag}_{k}"] = v
+    np.savez_compressed(OUT / "c5_replicate_slice.npz", **blob)
+    print("wrote c5_replicate_slice.npz", tmparr.shape)
+
+
 if __name__ == "__main__":
-    main()
-    make_resample_golden()
+    which = sys.argv[1:] or ["main", "resample", "c5"]
+    if "main" in which:
+        main()
+    if "resample" in which:
+        make_resample_golden()
+    if "c5" in which:
+        make_c5_golden()

@@ -1,0 +1,226 @@
+"""GPU: BASELINE.json configs[3] (c4: 256 taxa x 100k SNPs, 5e6-quartet batch) and configs[4] (c5: 128 taxa,
+~50k SNPs per bootstrap replicate) at full size, and the drop-in surface of INTEGRATION.md section 1
+(`tetrad_amd.resolve_quartets`), called the way the reference's distributor calls it
+(run_inference.py:219-220)."""
+import zlib
+from itertools import combinations, islice
+
+import numpy as np
+import pytest
+
+from conftest import load_golden
+from test_gpu_parity import assert_close, check_against
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def engine():
+    from tetrad_amd.engine import QuartetEngine
+    eng = QuartetEngine(0)
+    yield eng
+    eng.close()
+
+
+@pytest.fixture(scope="module")
+def c4_data():
+    from tetrad_amd import synth
+    T, S, _ = synth.CONFIGS["c4"]
+    return synth.simulate_tmparr(T, S, synth.CONFIG_SEEDS["c4"])
+
+
+def test_c4_full_batch_properties_and_oracle_sample(engine, oracle, c4_data):
+    """The whole c4 batch -- 5e6 random quartets of 256 x 100k in ONE scan batch (5 GB count slab), results
+    delivered to host arrays in pieces -- then size-independent properties and an oracle sample:
+    (1) rows of the big batch == the same quartets resolved alone (batch invariance, bitwise);
+    (2) no flagged row, 0 < nsnps <= nloci; (3) relabelling symmetry; (4) oracle on 300 rows, both modes."""
+    import torch
+    from math import comb
+    from tetrad_amd import synth
+    tmparr, tmpmap = c4_data
+    T, S = tmparr.shape
+    Q = 5_000_000
+    engine.set_data(tmparr, tmpmap)
+    ranks = np.random.default_rng(synth.CONFIG_SEEDS["c4"] + 1000).choice(comb(T, 4), size=Q, replace=False)
+    dev = torch.device("cuda:0")
+    d_r = torch.from_numpy(ranks.astype(np.int64)).to(dev)
+    d_q = torch.empty((Q, 4), dtype=torch.int32, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+    engine.unrank_dev(d_r.data_ptr(), Q, d_q.data_ptr(), stream)
+    torch.cuda.synchronize()
+    rstat, rscor, flags = engine.resolve_to_host(d_q.data_ptr(), Q, True)
+    nloci = len(np.unique(tmpmap[:, 0]))
+    assert (flags == 0).all(), "benchmark data must have no degenerate / zero-data / unconverged rows"
+    assert (rstat[:, 1] > 0).all() and (rstat[:, 1] <= nloci).all() and (rstat[:, 0] <= 2).all()
+    pick = np.random.default_rng(5).choice(Q, size=3000, replace=False)
+    pick[:3] = [0, Q - 1, Q // 2]
+    q = synth.unrank_quartets(ranks[pick], T)
+    np.testing.assert_array_equal(d_q[torch.from_numpy(pick).to(dev)].cpu().numpy().view(np.uint32), q)
+    r1, s1, f1 = engine.resolve(q, True)
+    np.testing.assert_array_equal(r1, rstat[pick])
+    np.testing.assert_array_equal(s1, rscor[pick])
+    # relabelling symmetry at this size (swapping taxa c<->d swaps flattenings 1 and 2)
+    r2, s2, _ = engine.resolve(q[:, [0, 1, 3, 2]], True)
+    np.testing.assert_array_equal(r2[:, 1], r1[:, 1])
+    np.testing.assert_array_equal(r2[:, 0], np.array([0, 2, 1])[r1[:, 0]])
+    assert_close(s2[:, [0, 2, 1]], s1, np.abs(s1).max(axis=1, keepdims=True) * 1e3, "scores under c<->d swap")
+    for sub in (True, False):
+        got = engine.resolve(q[:300], sub)
+        _, o_rstat, o_rscor, o = oracle.new_infer_resolved_quartets(tmparr, tmpmap, q[:300], sub, debug=True)
+        assert (got[2] == 0).all() and (o["flags"] == 0).all()
+        np.testing.assert_array_equal(got[0], o_rstat)
+        assert_close(got[1], o_rscor, o["svds"].max(axis=(1, 2))[:, None], "scores")
+
+
+def test_c4_batch_and_chunk_invariance(engine, c4_data):
+    """>= 1e5 quartets of c4: scan batches of 40k, singular-value chunks of 7k and the single-stream stage give
+    bitwise the rows of the default pass; full mode too."""
+    from tetrad_amd import synth
+    tmparr, tmpmap = c4_data
+    engine.set_data(tmparr, tmpmap)
+    q = synth.random_quartets(256, 120_000, seed=44)
+    for sub in (True, False):
+        base = engine.resolve(q, sub)
+        assert (base[2] == 0).all()
+        try:
+            for opts in ({"batch": 40_000}, {"svd_chunk": 7_000}, {"svd_streams": 1, "svd_chunk": 50_000}):
+                for k, v in opts.items():
+                    engine.set_option(k, v)
+                got = engine.resolve(q, sub)
+                for a, b in zip(base, got):
+                    np.testing.assert_array_equal(a, b)
+                for k in opts:
+                    engine.set_option(k, 0)
+        finally:
+            for k in ("batch", "svd_chunk", "svd_streams"):
+                engine.set_option(k, 0)
+
+
+def _c5_reference_replicate():
+    """The replicate the golden file was made from, rebuilt with the oracle's restatement of the reference's
+    resampler (pinned bit-for-bit against the reference's code) and checked against the stored CRCs."""
+    from oracle import resample as R
+    from tetrad_amd import synth
+    g = load_golden("c5_replicate_slice")
+    seqarr, maparr, spans = synth.make_c5_source()
+    tmparr, tmpmap = R.resample(seqarr, spans, g["lidxs"], seed=int(g["seed_resample"]))
+    tmparr = R.recode(R.resolve_ambigs(tmparr, seed=int(g["seed_ambig"])))
+    assert tuple(g["replicate_shape"]) == tmparr.shape
+    assert zlib.crc32(tmparr.tobytes()) == int(g["replicate_crc32"])
+    assert zlib.crc32(np.ascontiguousarray(tmpmap).tobytes()) == int(g["tmpmap_crc32"])
+    return g, seqarr, spans, tmparr, tmpmap
+
+
+def test_c5_reference_replicate_slice(engine):
+    """c5 shape: a bootstrap replicate made by the reference's own resampler, reference outputs for 12 quartets."""
+    g, _, _, tmparr, tmpmap = _c5_reference_replicate()
+    engine.set_data(tmparr, tmpmap)
+    for mode in ("full", "sub"):
+        rstat, rscor, flags, dbg = engine.resolve(g["quartets"], mode == "sub", debug=True)
+        nok, ndeg = check_against(g, mode, rstat, rscor, flags, dbg)
+        assert ndeg == 0
+
+
+def test_c5_size_device_replicate_vs_oracle(engine, oracle):
+    """One c5-size replicate built ON THE DEVICE (128 taxa, ~50k sites: locus resample + shuffle + IUPAC
+    resolution), exported, structurally valid for a sample of loci, and 2,500 quartets resolved on it
+    == the oracle on the exported replicate."""
+    from oracle import resample as R
+    from tetrad_amd import bootstrap, synth
+    seqarr, maparr, spans = synth.make_c5_source()
+    engine.set_source(seqarr, spans)
+    rng = np.random.default_rng(synth.CONFIG_SEEDS["c5"])
+    lidxs, s1, s2 = bootstrap.draw_replicate(len(spans), rng)
+    S = engine.bootstrap(lidxs, s1, s2)
+    tmparr, tmpmap = engine.get_data()
+    widths = spans[lidxs, 1] - spans[lidxs, 0]
+    assert tmparr.shape == (128, S) and S == int(widths.sum()) and 40_000 < S < 60_000
+    np.testing.assert_array_equal(tmpmap[:, 0], np.repeat(np.arange(len(lidxs)), widths))
+    # structural validity (every output column is a resolved column of its source locus) on the first 300 loci
+    n = 300
+    sub_S = int(widths[:n].sum())
+    R.check_replicate(seqarr, spans, lidxs[:n], tmparr[:, :sub_S], tmpmap[:sub_S])
+    q = synth.random_quartets(128, 2500, seed=55)
+    for sub in (True, False):
+        rstat, rscor, flags = engine.resolve(q, sub)
+        _, o_rstat, o_rscor, o = oracle.new_infer_resolved_quartets(tmparr, tmpmap, q, sub, debug=True)
+        assert (flags == 0).all() and (o["flags"] == 0).all()
+        np.testing.assert_array_equal(rstat, o_rstat)
+        assert_close(rscor, o_rscor, o["svds"].max(axis=(1, 2))[:, None], "scores")
+
+
+# ---------------------------------------------------------------------------------------------------
+# drop-in surface
+# ---------------------------------------------------------------------------------------------------
+def test_infer_resolved_quartets_as_the_distributor_calls_it(tmp_path):
+    """run_inference.py:219-220: `infer_resolved_quartets(database_file, nsamples, chunk, subsample_snps)` with
+    `chunk` an islice over combinations -> the reference's own triple for c1, chunk by chunk."""
+    from tetrad_amd import resolve_quartets as RQ
+    g = load_golden("c1_T16_S5000")
+    db = tmp_path / "snps.npz"
+    np.savez(db, tmparr=g["tmparr"], tmpmap=g["tmpmap"])
+    for sub, tag in ((True, "sub"), (False, "full")):
+        rows = []
+        for start in range(0, 1820, 455):                       # get_chunksize(1820, 4)
+            chunk = islice(combinations(range(16), 4), start, start + 455)     # combinations.py:40-55
+            rq, rstat, rscor = RQ.infer_resolved_quartets(db, 16, chunk, sub)
+            assert rq.dtype == np.uint32 and rstat.dtype == np.uint32 and rscor.dtype == np.float64
+            assert rq.shape == (455, 4) and rstat.shape == (455, 2) and rscor.shape == (455, 3)
+            rows.append((rq, rstat, rscor))
+        rq, rstat, rscor = (np.concatenate([r[i] for r in rows]) for i in range(3))
+        np.testing.assert_array_equal(rq, g["quartets"])
+        np.testing.assert_array_equal(rstat, g[f"{tag}_rstat"])
+        assert_close(rscor, g[f"{tag}_rscor"], np.abs(g[f"{tag}_rscor"]).max(), "scores")
+
+
+def test_new_infer_resolved_quartets_residency_is_safe(oracle):
+    """The mirror uploads once per replicate -- and again whenever what it uploaded is no longer what the
+    device holds: (1) somebody replaced the replicate through the shared engine, (2) the array was
+    refilled in place, (3) a different array with the same id/shape came along."""
+    from tetrad_amd import resolve_quartets as RQ
+    gA, gB = load_golden("tree_T12_S2000"), load_golden("dense_T8_S400")
+    A, mapA, qA = gA["tmparr"].copy(), gA["tmpmap"].copy(), gA["quartets"][:60]
+    eng = RQ.get_engine(0)
+    q, rstat, rscor = RQ.new_infer_resolved_quartets(A, mapA, qA, True)
+    np.testing.assert_array_equal(rstat, gA["sub_rstat"][:60])
+    gen = eng.data_generation
+    RQ.new_infer_resolved_quartets(A, mapA, qA, False)
+    assert eng.data_generation == gen, "second chunk of the same replicate must not upload again"
+    # (1) replicate replaced behind the mirror's back
+    eng.set_data(gB["tmparr"], gB["tmpmap"])
+    _, rstat, _ = RQ.new_infer_resolved_quartets(A, mapA, qA, True)
+    np.testing.assert_array_equal(rstat, gA["sub_rstat"][:60])
+    # (2) refilled in place: same id, same shape, new content
+    rng = np.random.default_rng(1)
+    A[:] = rng.permutation(A.T).T
+    _, rstat, rscor = RQ.new_infer_resolved_quartets(A, mapA, qA, True)
+    _, o_rstat, o_rscor = oracle.new_infer_resolved_quartets(A, mapA, qA, True)
+    np.testing.assert_array_equal(rstat[:, 1], o_rstat[:, 1])
+    assert_close(rscor, o_rscor, np.abs(o_rscor).max(), "scores after in-place refill")
+    # an explicit replicate token skips the content fingerprint: same token = same replicate, by contract
+    gen = eng.data_generation
+    RQ.new_infer_resolved_quartets(A, mapA, qA, True, replicate_token=("rep", 3))
+    RQ.new_infer_resolved_quartets(A, mapA, qA, True, replicate_token=("rep", 3))
+    assert eng.data_generation == gen + 1
+    RQ.invalidate()
+    RQ.new_infer_resolved_quartets(A, mapA, qA, True, replicate_token=("rep", 3))
+    assert eng.data_generation == gen + 2
+
+
+@pytest.mark.parametrize("case", ["dense_T8_S400", "carry_T6_S2500", "edge_T7_S130"])
+def test_kernel_level_mirrors(case):
+    """subsample_chunk_to_matrices / full_chunk_to_matrices(seqs, locus, mask) exactly as
+    resolve_quartets.py:212-223 calls them -> the reference's u32[3,16,16]."""
+    from tetrad_amd import resolve_quartets as RQ
+    g = load_golden(case)
+    tmparr, tmpmap = g["tmparr"], g["tmpmap"]
+    for qi in (0, len(g["quartets"]) // 2, len(g["quartets"]) - 1):
+        sidx = g["quartets"][qi]
+        seqs = tmparr[sidx, :]                                   # :212
+        nmask0 = np.sum(seqs >= 78, axis=0)                      # :216
+        nmask1 = np.sum(seqs == seqs[0], axis=0) == 4            # :218
+        mask = nmask0 + nmask1                                   # :221
+        got = RQ.subsample_chunk_to_matrices(seqs, tmpmap[:, 0], mask)
+        assert got.dtype == np.uint32 and got.shape == (3, 16, 16)
+        np.testing.assert_array_equal(got, g["sub_cmats"][qi])
+        np.testing.assert_array_equal(RQ.full_chunk_to_matrices(seqs, tmpmap[:, 0], mask), g["full_cmats"][qi])

@@ -54,7 +54,15 @@ def check_against(g, mode, rstat, rscor, flags, dbg):
     # topology: bit exact wherever the argmin is not decided by SVD rounding noise
     s = np.sort(ref_rscor, axis=1)
     ref_deg = (s[:, 1] - s[:, 0]) <= 1e-9 * smax
-    ok = ~zero & ~ref_deg & ((flags & 2) == 0)
+    dev_deg = (flags & 2) != 0
+    if f"{mode}_cmats" in g:
+        # the device may only excuse itself where the reference's own argmin is noise-decided: every row it
+        # flags must have a reference gap within twice the flag threshold (an over-eager flag would hide a
+        # wrong argmin)
+        over = dev_deg & ~zero & ((s[:, 1] - s[:, 0]) > 2e-9 * smax)
+        assert not over.any(), f"device flags {int(over.sum())} rows whose reference scores are well separated"
+    assert ((flags & 8) == 0).all(), "singular-value iteration hit its sweep cap"
+    ok = ~zero & ~ref_deg & ~dev_deg
     np.testing.assert_array_equal(rstat[ok, 0], ref_rstat[ok, 0])
     return int(ok.sum()), int((~zero & ~ok).sum())
 
@@ -79,9 +87,9 @@ def test_c1_full_run(engine, mode):
     np.testing.assert_array_equal(rstat, g[f"{mode}_rstat"])
 
 
-@pytest.mark.parametrize("cfg", ["c2", "c3"])
+@pytest.mark.parametrize("cfg", ["c2", "c3", "c4"])
 def test_config_slices(engine, cfg):
-    """Reference outputs for a few quartets of the c2 / c3 benchmark inputs (regenerated from the seed)."""
+    """Reference outputs for a few quartets of the c2 / c3 / c4 benchmark inputs (regenerated from the seed)."""
     from tetrad_amd import synth
     g = load_golden(f"{cfg}_slice")
     T, S, _ = synth.CONFIGS[cfg]

@@ -78,3 +78,42 @@ def test_flattenings_are_tensor_transposes(oracle):
     C = cm[:, 0].reshape(-1, 4, 4, 4, 4)
     np.testing.assert_array_equal(cm[:, 1], C.transpose(0, 1, 3, 2, 4).reshape(-1, 16, 16))
     np.testing.assert_array_equal(cm[:, 2], C.transpose(0, 1, 4, 2, 3).reshape(-1, 16, 16))
+
+
+@pytest.mark.parametrize("cfg", ["c2", "c3", "c4"])
+def test_oracle_matches_reference_on_config_slices(oracle, cfg):
+    """Reference outputs for a few quartets of the BASELINE.json benchmark inputs (regenerated from the seed)."""
+    from tetrad_amd import synth
+    g = load_golden(f"{cfg}_slice")
+    T, S, _ = synth.CONFIGS[cfg]
+    tmparr, tmpmap = synth.simulate_tmparr(T, S, synth.CONFIG_SEEDS[cfg])
+    for mode in ("full", "sub"):
+        _, rstat, rscor, dbg = oracle.new_infer_resolved_quartets(tmparr, tmpmap, g["quartets"], mode == "sub", debug=True)
+        assert not g[f"{mode}_zero_data"].any()
+        np.testing.assert_array_equal(dbg["cmats"], g[f"{mode}_cmats"])
+        np.testing.assert_array_equal(rstat, g[f"{mode}_rstat"])
+        np.testing.assert_array_equal(rscor, g[f"{mode}_rscor"])
+
+
+def test_oracle_matches_reference_on_c5_replicate(oracle):
+    """BASELINE.json configs[4]: the bootstrap replicate the reference's resampler made from the c5 source is
+    rebuilt by the oracle's restatement (CRC-checked), and the oracle worker reproduces the reference's rows."""
+    import zlib
+    from oracle import resample as R
+    from tetrad_amd import synth
+    g = load_golden("c5_replicate_slice")
+    seqarr, maparr, spans = synth.make_c5_source()
+    np.testing.assert_array_equal(R.get_spans(maparr), spans)
+    tmparr, tmpmap = R.resample(seqarr, spans, g["lidxs"], seed=int(g["seed_resample"]))
+    tmparr = R.recode(R.resolve_ambigs(tmparr, seed=int(g["seed_ambig"])))
+    assert zlib.crc32(tmparr.tobytes()) == int(g["replicate_crc32"])
+    assert zlib.crc32(np.ascontiguousarray(tmpmap).tobytes()) == int(g["tmpmap_crc32"])
+    # the same draws on the project Generator (run_inference.py:117-123)
+    rng = np.random.default_rng(synth.CONFIG_SEEDS["c5"])
+    np.testing.assert_array_equal(rng.choice(len(spans), len(spans), replace=True), g["lidxs"])
+    assert int(rng.integers(2**31)) == int(g["seed_resample"]) and int(rng.integers(2**31)) == int(g["seed_ambig"])
+    for mode in ("full", "sub"):
+        _, rstat, rscor, dbg = oracle.new_infer_resolved_quartets(tmparr, tmpmap, g["quartets"], mode == "sub", debug=True)
+        np.testing.assert_array_equal(dbg["cmats"], g[f"{mode}_cmats"])
+        np.testing.assert_array_equal(rstat, g[f"{mode}_rstat"])
+        np.testing.assert_array_equal(rscor, g[f"{mode}_rscor"])

@@ -83,6 +83,25 @@ def simulate_tmparr(T: int, S: int, seed: int, p: float = 0.05, missing: float =
     return tmparr, tmpmap
 
 
+def make_c5_source(T: int | None = None, S: int | None = None, seed: int | None = None, ambiguous: float = 0.01):
+    """The project-level inputs of the bootstrap flow (BASELINE.json configs[4], c3 shape): `seqarr`
+    u8[T,S] of ASCII bases with `ambiguous` of the cells replaced by IUPAC two-base codes and N for
+    missing (write_database.py:157-159), the snpsmap-style `maparr` u32[S,2] and the locus spans
+    i64[nloci,2] (jit/get_spans.py)."""
+    T0, S0, _ = CONFIGS["c3"]
+    T, S = T or T0, S or S0
+    tmparr, tmpmap = simulate_tmparr(T, S, CONFIG_SEEDS["c5"] if seed is None else seed)
+    ascii_ = np.array([65, 67, 71, 84], np.uint8)
+    seqarr = np.where(tmparr <= 3, ascii_[np.minimum(tmparr, 3)], 78).astype(np.uint8)
+    rs = np.random.default_rng(0)
+    amb = rs.random(seqarr.shape) < ambiguous
+    seqarr[amb] = rs.choice(np.array([82, 75, 83, 89, 87, 77], np.uint8), size=int(amb.sum()))
+    loc = tmpmap[:, 0]
+    starts = np.flatnonzero(np.concatenate([[True], loc[1:] != loc[:-1]]))
+    spans = np.stack([starts, np.concatenate([starts[1:], [S]])], axis=1).astype(np.int64)
+    return seqarr, tmpmap, spans
+
+
 def all_quartets(T: int) -> np.ndarray:
     """All C(T,4) quartets in lexicographic order (combinations.py:40-55)."""
     n = comb(T, 4)

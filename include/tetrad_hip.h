@@ -100,6 +100,11 @@ int tq_set_source(tq_ctx *ctx, const uint8_t *seqarr, int64_t T, int64_t S0,
                   const int64_t *spans, int64_t nloci);
 int tq_bootstrap(tq_ctx *ctx, const int64_t *lidxs, int64_t n, uint64_t seed_shuffle,
                  uint64_t seed_ambig, int64_t *out_S);
+/* Same, enqueued on `stream` without waiting (the replicate length is computed on the host from the
+ * spans): the replicate of iteration k+1 is built right behind the kernels of iteration k.  Resolve
+ * calls for the new replicate must be ordered after it (same stream, or an event).              */
+int tq_bootstrap_async(tq_ctx *ctx, const int64_t *lidxs, int64_t n, uint64_t seed_shuffle,
+                       uint64_t seed_ambig, int64_t *out_S, void *stream);
 int tq_get_data(tq_ctx *ctx, uint8_t *tmparr, uint32_t *tmpmap);
 int tq_data_shape(tq_ctx *ctx, int64_t *T, int64_t *S);
 
@@ -158,6 +163,15 @@ int tq_svd_dev(tq_ctx *ctx, int64_t q0, int64_t n, uint32_t *d_rstat, double *d_
  * lexicographic ranks (combinations.py:94-114) into d_quartets.                    */
 int tq_unrank_dev(tq_ctx *ctx, const uint64_t *d_ranks, int64_t Q, uint32_t *d_quartets,
                   void *stream);
+
+/* Opt-in quartet sampler on the device: Q DISTINCT quartets drawn uniformly from the C(T,4) of the resident
+ * (or source) matrix, in random order, written to d_quartets (u32[Q,4]) and -- if d_ranks is not NULL -- their
+ * lexicographic ranks to d_ranks (u64[Q]).  Same distribution as
+ * random_combination_sample_via_index (combinations.py:109-114: rng.choice(C(T,4), size, replace=False)
+ * + unranking) but NOT the project Generator's stream (a keyed permutation of the rank space,
+ * counter-based): for runs that do not need to reproduce a reference run's sample.               */
+int tq_sample_quartets_dev(tq_ctx *ctx, uint64_t seed, int64_t Q, uint64_t *d_ranks,
+                           uint32_t *d_quartets, void *stream);
 
 /* Kernel-level outputs for parity tests (host buffers, synchronous); any of the
  * debug pointers may be NULL.

@@ -37,6 +37,21 @@ dist.barrier()
 chunks = [qr[i:i + 400].tolist() for i in range(0, 1501, 400)]
 D.distributor(db, out + ".tsv", 16, iter(chunks), True, None)
 dist.barrier()
+# the replicate loop on two ranks: rows of every replicate to rank 0
+from tetrad_amd import synth
+from tetrad_amd.resolve_quartets import get_engine
+from tetrad_amd.replicates import ReplicateRunner
+seqarr, maparr, spans = synth.make_c5_source(T=14, S=6000, seed=8, ambiguous=0.02)
+for sampler in ("host", "device"):
+    got = {}
+    runner = ReplicateRunner(get_engine(0), seqarr, spans, 701, seed=5, sampler=sampler, pieces=2)
+    runner.run(3, True, on_result=lambda k, S, a, b, c: got.__setitem__(k, (a.copy(), b.copy(), c.copy())))
+    runner.close()
+    if rank == 0:
+        np.savez(out + f".reps.{sampler}.npz", **{f"{n}{k}": got[k][i] for k in got for i, n in enumerate(("rstat", "rscor", "flags"))})
+    else:
+        assert not got
+dist.barrier()
 dist.destroy_process_group()
 '''
 
@@ -72,3 +87,19 @@ def test_two_ranks_with_the_engine_equal_one_engine(tmp_path):
             np.testing.assert_array_equal(z["flags"], flags)
     rstat, rscor, _ = eng.resolve(q, True)
     assert Path(out + ".tsv").read_text() == D.format_tsv(q, rscor, rstat)
+    eng.close()
+    # two-rank replicate loop == one-rank replicate loop, bitwise
+    from tetrad_amd import synth
+    from tetrad_amd.replicates import ReplicateRunner
+    seqarr, maparr, spans = synth.make_c5_source(T=14, S=6000, seed=8, ambiguous=0.02)
+    for sampler in ("host", "device"):
+        one = {}
+        with QuartetEngine(0) as e1:
+            runner = ReplicateRunner(e1, seqarr, spans, 701, seed=5, sampler=sampler)
+            runner.run(3, True, on_result=lambda k, S, a, b, c: one.__setitem__(k, (a.copy(), b.copy(), c.copy())))
+            runner.close()
+        z = np.load(out + f".reps.{sampler}.npz")
+        for k in range(3):
+            np.testing.assert_array_equal(z[f"rstat{k}"], one[k][0])
+            np.testing.assert_array_equal(z[f"rscor{k}"], one[k][1])
+            np.testing.assert_array_equal(z[f"flags{k}"], one[k][2])

@@ -1,0 +1,103 @@
+"""GPU: the bootstrap-replicate loop (tetrad_amd/replicates.py, mirror of run_inference.py:378-407) and the
+opt-in device quartet sampler."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _small_source():
+    from tetrad_amd import synth
+    return synth.make_c5_source(T=14, S=6000, seed=8, ambiguous=0.02)
+
+
+def test_device_sampler_draws_distinct_uniform_quartets():
+    """tq_sample_quartets_dev: Q distinct ranks < C(T,4), quartets = their lexicographic unranking, uniform
+    over the rank space and over taxa, deterministic in the seed, different for different seeds."""
+    import torch
+    from math import comb
+    from tetrad_amd import synth
+    from tetrad_amd.engine import QuartetEngine
+    tmparr, tmpmap = synth.simulate_tmparr(40, 300, seed=1)
+    dev = torch.device("cuda:0")
+    with QuartetEngine(0) as eng:
+        eng.set_data(tmparr, tmpmap)
+        N = comb(40, 4)                                             # 91 390
+        for Q in (1, 1000, N // 3, N):                              # N: the whole space, a permutation
+            d_q = torch.empty((Q, 4), dtype=torch.int32, device=dev)
+            d_r = torch.empty(Q, dtype=torch.int64, device=dev)
+            eng.sample_quartets_dev(12345, Q, d_q.data_ptr(), d_r.data_ptr())
+            torch.cuda.synchronize()
+            r = d_r.cpu().numpy()
+            assert r.min() >= 0 and r.max() < N and len(np.unique(r)) == Q
+            np.testing.assert_array_equal(d_q.cpu().numpy().view(np.uint32), synth.unrank_quartets(r, 40))
+        Q = N // 3
+        d_q2 = torch.empty((Q, 4), dtype=torch.int32, device=dev)
+        d_r2 = torch.empty(Q, dtype=torch.int64, device=dev)
+        eng.sample_quartets_dev(12345, Q, d_q2.data_ptr(), d_r2.data_ptr())
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(d_r2.cpu().numpy(), r[:Q])    # a prefix of the same permutation
+        eng.sample_quartets_dev(12346, Q, d_q2.data_ptr(), d_r2.data_ptr())
+        torch.cuda.synchronize()
+        r2 = d_r2.cpu().numpy()
+        assert len(np.intersect1d(r2, r[:Q])) < 0.45 * Q            # ~1/3 expected for independent samples
+        # uniformity: 64 equal buckets of the rank space, chi-square against the hypergeometric-ish expectation
+        counts = np.bincount((r2.astype(np.float64) / N * 64).astype(int), minlength=64)
+        exp = Q / 64
+        assert ((counts - exp) ** 2 / exp).sum() < 64 * 2.0
+        # the order is random too: no monotone runs
+        assert abs(np.corrcoef(np.arange(Q), r2)[0, 1]) < 0.02
+        with pytest.raises(Exception):
+            eng.sample_quartets_dev(1, N + 1, d_q2.data_ptr(), 0)
+
+
+@pytest.mark.parametrize("sampler", ["host", "device"])
+def test_replicate_runner_equals_step_by_step(oracle, sampler):
+    """Four replicates through the pipelined runner == the same draws applied step by step with a second
+    engine (synchronous bootstrap + resolve), and == the oracle on the exported replicate for a sample; the
+    Generator ends where the reference's would."""
+    import torch
+    from math import comb
+    from tetrad_amd import bootstrap, synth
+    from tetrad_amd.engine import QuartetEngine
+    from tetrad_amd.replicates import ReplicateRunner
+    seqarr, maparr, spans = _small_source()
+    Q, nreps, seed = 700, 4, 99
+    got = {}
+    with QuartetEngine(0) as eng:
+        runner = ReplicateRunner(eng, seqarr, spans, Q, seed=seed, sampler=sampler, ahead=2)
+        stats = runner.run(nreps, True, on_result=lambda k, S, a, b, c: got.__setitem__(k, (S, a.copy(), b.copy(), c.copy())))
+        final_state = runner.rng.bit_generator.state
+        runner.close()
+    assert sorted(got) == list(range(nreps)) and len(stats["sites"]) == nreps
+    rng = np.random.default_rng(seed)
+    dev = torch.device("cuda:0")
+    with QuartetEngine(0) as eng:
+        eng.set_source(seqarr, spans)
+        for k in range(nreps):
+            lidxs, s1, s2 = bootstrap.draw_replicate(len(spans), rng)
+            S = eng.bootstrap(lidxs, s1, s2)
+            if sampler == "host":
+                idx = rng.choice(comb(14, 4), size=Q, replace=False)
+                q = synth.unrank_quartets(idx, 14)
+            else:
+                sd = int(rng.integers(2**63))
+                d_q = torch.empty((Q, 4), dtype=torch.int32, device=dev)
+                eng.sample_quartets_dev(sd, Q, d_q.data_ptr(), 0)
+                torch.cuda.synchronize()
+                q = d_q.cpu().numpy().view(np.uint32)
+                assert len(np.unique(q, axis=0)) == Q
+            rstat, rscor, flags = eng.resolve(q, True)
+            assert got[k][0] == S
+            np.testing.assert_array_equal(got[k][1], rstat)
+            np.testing.assert_array_equal(got[k][2], rscor)
+            np.testing.assert_array_equal(got[k][3], flags)
+            if k == nreps - 1:
+                tmparr, tmpmap = eng.get_data()
+                _, o_rstat, o_rscor, o = oracle.new_infer_resolved_quartets(tmparr, tmpmap, q[:200], True, debug=True)
+                np.testing.assert_array_equal(rstat[:200, 1], o_rstat[:, 1])
+                ok = ((flags[:200] | o["flags"]) & 3) == 0
+                np.testing.assert_array_equal(rstat[:200][ok, 0], o_rstat[ok, 0])
+    # the producer may have drawn ahead, but never beyond the replicates it was asked for
+    assert final_state == rng.bit_generator.state
+    assert runner.rng_state_after[-1] == rng.bit_generator.state

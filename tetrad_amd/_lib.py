@@ -27,7 +27,7 @@ FLAG_ZERO_DATA, FLAG_DEGENERATE, FLAG_BAD_INDEX, FLAG_NO_CONVERGENCE = 1, 2, 4, 
 #: every symbol include/tetrad_hip.h declares (checked by tests/test_cabi_symbols.py)
 SYMBOLS = [
     "tq_create", "tq_destroy", "tq_last_error", "tq_set_data", "tq_resolve",
-    "tq_set_source", "tq_bootstrap", "tq_get_data", "tq_data_shape",
+    "tq_set_source", "tq_bootstrap", "tq_bootstrap_async", "tq_sample_quartets_dev", "tq_get_data", "tq_data_shape",
     "tq_host_alloc", "tq_host_free", "tq_resolve_to_host", "tq_scan_dev", "tq_svd_dev",
     "tq_resolve_dev", "tq_resolve_range_dev", "tq_unrank_dev", "tq_resolve_debug",
     "tq_timing_enable", "tq_timing_read", "tq_timing_read_split", "tq_timing_read_kernels",
@@ -90,6 +90,10 @@ def load() -> ctypes.CDLL:
     lib.tq_set_source.restype = i32
     lib.tq_bootstrap.argtypes = [vp, vp, i64, c.c_uint64, c.c_uint64, c.POINTER(i64)]
     lib.tq_bootstrap.restype = i32
+    lib.tq_bootstrap_async.argtypes = [vp, vp, i64, c.c_uint64, c.c_uint64, c.POINTER(i64), vp]
+    lib.tq_bootstrap_async.restype = i32
+    lib.tq_sample_quartets_dev.argtypes = [vp, c.c_uint64, i64, vp, vp, vp]
+    lib.tq_sample_quartets_dev.restype = i32
     lib.tq_get_data.argtypes = [vp, vp, vp]
     lib.tq_get_data.restype = i32
     lib.tq_data_shape.argtypes = [vp, c.POINTER(i64), c.POINTER(i64)]

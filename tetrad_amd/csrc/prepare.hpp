@@ -95,3 +95,61 @@ __global__ void tq_key_kernel(const uint32_t *__restrict__ quartets, int64_t Q, 
     idx[i] = (uint32_t)i;
 }
 
+
+// ------------------------------------------------------------------------------------
+// Random quartet sample on the device (opt-in): Q distinct lexicographic
+// ranks drawn uniformly from C(T,4), in random order -- the distribution of
+// `rng.choice(C(T,4), size=Q, replace=False)` (combinations.py:109-114) -- without the host's 30 ms draw.
+// Rank i of the sample is pi(i), pi = a keyed pseudo-random permutation of [0, N): a 6-round Feistel
+// network on the smallest even-split bit width >= log2 N, cycle-walked into range (a permutation of
+// [0, 2^b) restricted to [0, N) by iterating until the value lands below N is a permutation of [0, N)).
+// The first Q values of a random permutation are a uniform ordered sample without replacement.  Not the
+// project Generator's stream: statistically equivalent, documented as such (like the device bootstrap).
+// ------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t feistel_round(uint32_t x, uint32_t key)
+{
+    x ^= key;
+    x *= 0x7FEB352Du;              // lowbias32 (two multiply-xorshift rounds)
+    x ^= x >> 15;
+    x *= 0x846CA68Bu;
+    x ^= x >> 16;
+    return x;
+}
+
+__device__ __forceinline__ uint64_t feistel_permute(uint64_t v, int half_bits, uint64_t seed)
+{
+    const uint32_t mask = half_bits >= 32 ? 0xFFFFFFFFu : ((1u << half_bits) - 1u);
+    uint32_t L = (uint32_t)(v >> half_bits) & mask, R = (uint32_t)v & mask;
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+        const uint32_t key = (uint32_t)(seed >> (8 * (r & 3))) + 0x9E3779B9u * (uint32_t)(r + 1) + (uint32_t)(seed >> 32);
+        const uint32_t t = L ^ (feistel_round(R, key) & mask);
+        L = R;
+        R = t;
+    }
+    return ((uint64_t)L << half_bits) | (uint64_t)R;
+}
+
+__global__ void tq_sample_kernel(uint64_t seed, uint64_t N, int half_bits, int64_t Q, int32_t T,
+                                 uint64_t *__restrict__ ranks_out, uint32_t *__restrict__ quartets)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= Q) return;
+    uint64_t v = (uint64_t)i;
+    do {                                    // expected < 4 rounds: 2^(2*half_bits) < 4N
+        v = feistel_permute(v, half_bits, seed);
+    } while (v >= N);
+    if (ranks_out) ranks_out[i] = v;
+    uint64_t index = v;
+    uint32_t out[4] = {0, 0, 0, 0};
+    int nsel = 0;
+    for (int t = 0; t < T && nsel < 4; ++t) {
+        uint64_t c = choose_k((uint64_t)(T - t - 1), 4 - nsel - 1);
+        if (c > index) {
+            out[nsel++] = (uint32_t)t;
+        } else {
+            index -= c;
+        }
+    }
+    reinterpret_cast<uint4 *>(quartets)[i] = make_uint4(out[0], out[1], out[2], out[3]);
+}

@@ -82,6 +82,10 @@ struct tq_ctx {
     int64_t *d_spans = nullptr;
     int64_t src_T = 0, src_S0 = 0, nloci = 0, max_width = 0;
     int64_t *d_lidxs = nullptr;     // [nloci]
+    std::vector<int64_t> h_spans;   // host copy of the spans (replicate lengths are computed on the host)
+    int64_t *h_lidx_stage[2] = {nullptr, nullptr};   // page-locked staging of the resampled locus indices
+    hipEvent_t ev_lidx[2] = {nullptr, nullptr};      // its H2D has been consumed
+    unsigned lidx_turn = 0;
     uint32_t *d_boot = nullptr;     // widths/offsets [nloci+1] | src_col [cap] | site_locus [cap]
     int64_t boot_cap = 0;
     void *d_boot_tmp = nullptr;
@@ -279,6 +283,12 @@ void free_source(tq_ctx *ctx)
     ctx->d_boot_tmp = nullptr;
     ctx->boot_cap = 0;
     ctx->nloci = 0;
+    for (int i = 0; i < 2; ++i) {
+        if (ctx->h_lidx_stage[i]) (void)pool().release(ctx->h_lidx_stage[i]);
+        if (ctx->ev_lidx[i]) (void)hipEventDestroy(ctx->ev_lidx[i]);
+        ctx->h_lidx_stage[i] = nullptr;
+        ctx->ev_lidx[i] = nullptr;
+    }
 }
 
 int ensure_scratch(tq_ctx *ctx, size_t bytes)
@@ -1253,6 +1263,16 @@ int tq_set_source(tq_ctx *ctx, const uint8_t *seqarr, int64_t T, int64_t S0, con
     TQ_HIP(ctx, hipMalloc((void **)&ctx->d_lidxs, (size_t)nloci * 8));
     TQ_HIP(ctx, hipMemcpy(ctx->d_seqarr, seqarr, (size_t)(T * S0), hipMemcpyHostToDevice));
     TQ_HIP(ctx, hipMemcpy(ctx->d_spans, spans, (size_t)nloci * 16, hipMemcpyHostToDevice));
+    try {
+        ctx->h_spans.assign(spans, spans + 2 * nloci);
+    } catch (const std::bad_alloc &) {
+        return fail(ctx, TQ_ERR_OOM, "tq_set_source: out of host memory");
+    }
+    for (int i = 0; i < 2; ++i) {
+        if (pool().alloc((size_t)nloci * 8, (void **)&ctx->h_lidx_stage[i]) != TQ_OK)
+            return fail(ctx, TQ_ERR_OOM, "tq_set_source: out of page-locked host memory");
+        TQ_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_lidx[i], hipEventDisableTiming));
+    }
     ctx->src_T = T;
     ctx->src_S0 = S0;
     ctx->nloci = nloci;
@@ -1260,22 +1280,27 @@ int tq_set_source(tq_ctx *ctx, const uint8_t *seqarr, int64_t T, int64_t S0, con
     return TQ_OK;
 }
 
-int tq_bootstrap(tq_ctx *ctx, const int64_t *lidxs, int64_t n, uint64_t seed_shuffle, uint64_t seed_ambig,
-                 int64_t *out_S)
+int tq_bootstrap_async(tq_ctx *ctx, const int64_t *lidxs, int64_t n, uint64_t seed_shuffle, uint64_t seed_ambig,
+                       int64_t *out_S, void *stream_)
 {
     if (!ctx) return TQ_ERR_INVALID_ARG;
     if (!ctx->d_seqarr) return fail(ctx, TQ_ERR_NO_DATA, "tq_set_source has not been called");
     if (!lidxs || n != ctx->nloci)
         return fail(ctx, TQ_ERR_INVALID_ARG, "tq_bootstrap: lidxs must hold nloci=%lld locus indices", (long long)ctx->nloci);
+    hipStream_t stream = (hipStream_t)stream_;
+    // replicate length on the host (jit/resample.py:7-17): no device round trip, the call stays asynchronous
     int64_t S = 0;
-    for (int64_t i = 0; i < n; ++i)
+    for (int64_t i = 0; i < n; ++i) {
         if (lidxs[i] < 0 || lidxs[i] >= ctx->nloci)
             return fail(ctx, TQ_ERR_INVALID_ARG, "tq_bootstrap: locus index %lld out of range", (long long)lidxs[i]);
+        S += ctx->h_spans[2 * lidxs[i] + 1] - ctx->h_spans[2 * lidxs[i]];
+    }
     TQ_HIP(ctx, hipSetDevice(ctx->device));
     const int64_t T = ctx->src_T;
     // worst-case replicate length; buffers grow only
     const int64_t cap = n * ctx->max_width;
     if (cap > ctx->boot_cap) {
+        TQ_HIP(ctx, hipDeviceSynchronize());
         if (ctx->d_boot) (void)hipFree(ctx->d_boot);
         if (ctx->d_boot_tmp) (void)hipFree(ctx->d_boot_tmp);
         ctx->d_boot = nullptr;
@@ -1292,21 +1317,11 @@ int tq_bootstrap(tq_ctx *ctx, const int64_t *lidxs, int64_t n, uint64_t seed_shu
         ctx->boot_tmp_bytes = tmp;
         ctx->boot_cap = cap;
     }
-    uint32_t *widths = ctx->d_boot, *offsets = widths + (n + 1);
-    uint32_t *src_col = offsets + (n + 1), *site_locus = src_col + ctx->boot_cap;
-    TQ_HIP(ctx, hipMemcpy(ctx->d_lidxs, lidxs, (size_t)n * 8, hipMemcpyHostToDevice));
-    TQ_HIP(ctx, hipMemset(widths + n, 0, sizeof(uint32_t)));
-    hipLaunchKernelGGL(tq_boot_width_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, ctx->d_spans,
-                       ctx->d_lidxs, n, ctx->nloci, widths);
-    size_t tmp = ctx->boot_tmp_bytes;
-    TQ_HIP(ctx, hipcub::DeviceScan::ExclusiveSum(ctx->d_boot_tmp, tmp, widths, offsets, (int)(n + 1)));
-    uint32_t total = 0;
-    TQ_HIP(ctx, hipMemcpy(&total, offsets + n, sizeof(uint32_t), hipMemcpyDeviceToHost));
-    S = (int64_t)total;
-    if (S < 1 || S > ctx->boot_cap) return fail(ctx, TQ_ERR_HIP, "tq_bootstrap: inconsistent replicate length %lld", (long long)S);
+    if (S < 1 || S > ctx->boot_cap) return fail(ctx, TQ_ERR_INVALID_ARG, "tq_bootstrap: replicate length %lld", (long long)S);
     const int64_t Sp = (int64_t)align_up((size_t)S, TILE);
     const int64_t W = Sp / 32;
     if (Sp > ctx->data_capacity || T != ctx->T) {
+        TQ_HIP(ctx, hipDeviceSynchronize());           // kernels of the previous replicate may still read the old buffers
         free_data(ctx);
         const int64_t capSp = (int64_t)align_up((size_t)(Sp + Sp / 8), TILE);   // head-room: replicate lengths vary
         TQ_HIP(ctx, hipMalloc((void **)&ctx->d_rows, (size_t)(T * capSp)));
@@ -1316,22 +1331,65 @@ int tq_bootstrap(tq_ctx *ctx, const int64_t *lidxs, int64_t n, uint64_t seed_shu
         ctx->plane_cap_W = capSp / 32;
         ctx->data_capacity = capSp;
     }
-    hipLaunchKernelGGL(tq_boot_perm_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, ctx->d_spans,
+    uint32_t *widths = ctx->d_boot, *offsets = widths + (n + 1);
+    uint32_t *src_col = offsets + (n + 1), *site_locus = src_col + ctx->boot_cap;
+    // locus indices through a page-locked staging piece (two in turn, so that the draws of the next replicate
+    // can be handed over while this copy is still queued)
+    const unsigned turn = ctx->lidx_turn++ & 1u;
+    TQ_HIP(ctx, hipEventSynchronize(ctx->ev_lidx[turn]));
+    memcpy(ctx->h_lidx_stage[turn], lidxs, (size_t)n * 8);
+    TQ_HIP(ctx, hipMemcpyAsync(ctx->d_lidxs, ctx->h_lidx_stage[turn], (size_t)n * 8, hipMemcpyHostToDevice, stream));
+    TQ_HIP(ctx, hipEventRecord(ctx->ev_lidx[turn], stream));
+    TQ_HIP(ctx, hipMemsetAsync(widths + n, 0, sizeof(uint32_t), stream));
+    hipLaunchKernelGGL(tq_boot_width_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, ctx->d_spans,
+                       ctx->d_lidxs, n, ctx->nloci, widths);
+    size_t tmp = ctx->boot_tmp_bytes;
+    TQ_HIP(ctx, hipcub::DeviceScan::ExclusiveSum(ctx->d_boot_tmp, tmp, widths, offsets, (int)(n + 1), stream));
+    hipLaunchKernelGGL(tq_boot_perm_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, ctx->d_spans,
                        ctx->d_lidxs, offsets, n, ctx->nloci, seed_shuffle, src_col, site_locus);
     const int64_t nw = T * W;
-    hipLaunchKernelGGL(tq_boot_build_kernel, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, 0, ctx->d_seqarr,
+    hipLaunchKernelGGL(tq_boot_build_kernel, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, stream, ctx->d_seqarr,
                        ctx->src_S0, src_col, site_locus, S, Sp, W, (int32_t)T, seed_ambig, ctx->d_rows, ctx->d_nib,
                        ctx->d_nib + (size_t)T * (size_t)ctx->data_capacity / 2,
                        ctx->d_planes, ctx->d_planes3, ctx->d_planes3 + (size_t)T * (size_t)ctx->plane_cap_W * 3);
     TQ_HIP(ctx, hipGetLastError());
-    TQ_HIP(ctx, hipDeviceSynchronize());
     ctx->T = T;
     ctx->S = S;
     ctx->Sp = Sp;
     ctx->W = W;
     ctx->have_data = true;
     ctx->locus_runs_ok = true;          // locus ids are the ordinals 0..n-1, one run each
+    ctx->scanned_Q = 0;
     if (out_S) *out_S = S;
+    return TQ_OK;
+}
+
+int tq_bootstrap(tq_ctx *ctx, const int64_t *lidxs, int64_t n, uint64_t seed_shuffle, uint64_t seed_ambig,
+                 int64_t *out_S)
+{
+    const int rc = tq_bootstrap_async(ctx, lidxs, n, seed_shuffle, seed_ambig, out_S, nullptr);
+    if (rc) return rc;
+    TQ_HIP(ctx, hipStreamSynchronize(nullptr));
+    return TQ_OK;
+}
+
+int tq_sample_quartets_dev(tq_ctx *ctx, uint64_t seed, int64_t Q, uint64_t *d_ranks, uint32_t *d_quartets, void *stream)
+{
+    if (!ctx) return TQ_ERR_INVALID_ARG;
+    if (!ctx->have_data && !ctx->d_seqarr) return fail(ctx, TQ_ERR_NO_DATA, "no data on the device (T unknown)");
+    if (Q < 0 || (Q > 0 && !d_quartets)) return fail(ctx, TQ_ERR_INVALID_ARG, "tq_sample_quartets_dev: NULL pointer or negative Q");
+    const uint64_t T = (uint64_t)(ctx->have_data ? ctx->T : ctx->src_T);
+    const uint64_t total = T < 4 ? 0 : T * (T - 1) / 2 * (T - 2) / 3 * (T - 3) / 4;
+    if ((uint64_t)Q > total)
+        return fail(ctx, TQ_ERR_INVALID_ARG, "cannot draw %lld distinct quartets from C(%llu,4)=%llu", (long long)Q,
+                    (unsigned long long)T, (unsigned long long)total);
+    if (Q == 0) return TQ_OK;
+    int half = 1;
+    while (half < 32 && (1ull << (2 * half)) < total) ++half;
+    TQ_HIP(ctx, hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(tq_sample_kernel, dim3((unsigned)((Q + 255) / 256)), dim3(256), 0, (hipStream_t)stream, seed, total,
+                       half, Q, (int32_t)T, d_ranks, d_quartets);
+    TQ_HIP(ctx, hipGetLastError());
     return TQ_OK;
 }
 
@@ -1341,6 +1399,7 @@ int tq_get_data(tq_ctx *ctx, uint8_t *tmparr, uint32_t *tmpmap)
     if (!ctx->have_data) return fail(ctx, TQ_ERR_NO_DATA, "no replicate on the device");
     if (!tmparr || !tmpmap) return fail(ctx, TQ_ERR_INVALID_ARG, "tq_get_data: NULL pointer");
     TQ_HIP(ctx, hipSetDevice(ctx->device));
+    TQ_HIP(ctx, hipDeviceSynchronize());     // a replicate may still be queued (tq_bootstrap_async) on any stream
     const int64_t T = ctx->T, S = ctx->S, W = ctx->W;
     const size_t bytes = align_up((size_t)(T * S), 256) + align_up((size_t)S * 8, 256) + align_up((size_t)(W + 1) * 8, 256);
     int rc = ensure_scratch(ctx, bytes);

@@ -119,13 +119,18 @@ class QuartetEngine:
         self._check(self._lib.tq_set_source(self._h, _ptr(seqarr), T, S0, _ptr(spans), spans.shape[0]))
         self.nloci = spans.shape[0]
 
-    def bootstrap(self, lidxs: np.ndarray, seed_shuffle: int, seed_ambig: int) -> int:
-        """Build the replicate for resampled loci `lidxs` on the device; returns its number of sites."""
+    def bootstrap(self, lidxs: np.ndarray, seed_shuffle: int, seed_ambig: int, stream: int | None = None) -> int:
+        """Build the replicate for resampled loci `lidxs` on the device; returns its number of sites.
+        With `stream` (a hipStream_t address, 0 = default stream) the call only enqueues."""
         lidxs = np.ascontiguousarray(lidxs, dtype=np.int64)
         S = ctypes.c_int64()
         self.data_generation += 1
-        self._check(self._lib.tq_bootstrap(self._h, _ptr(lidxs), lidxs.shape[0], int(seed_shuffle), int(seed_ambig),
-                                           ctypes.byref(S)))
+        if stream is None:
+            self._check(self._lib.tq_bootstrap(self._h, _ptr(lidxs), lidxs.shape[0], int(seed_shuffle),
+                                               int(seed_ambig), ctypes.byref(S)))
+        else:
+            self._check(self._lib.tq_bootstrap_async(self._h, _ptr(lidxs), lidxs.shape[0], int(seed_shuffle),
+                                                     int(seed_ambig), ctypes.byref(S), stream or None))
         T = ctypes.c_int64()
         self._check(self._lib.tq_data_shape(self._h, ctypes.byref(T), None))
         self.T, self.S = T.value, S.value
@@ -203,6 +208,11 @@ class QuartetEngine:
     def svd_dev(self, q0: int, n: int, d_rstat: int, d_rscor: int, d_flags: int = 0, stream: int = 0):
         """Stage 2 for rows [q0, q0+n) of the scanned batch; the pointers are the outputs OF ROW q0."""
         self._check(self._lib.tq_svd_dev(self._h, q0, n, d_rstat, d_rscor, d_flags or None, stream or None))
+
+    def sample_quartets_dev(self, seed: int, Q: int, d_quartets: int, d_ranks: int = 0, stream: int = 0):
+        """Q distinct quartets drawn uniformly from C(T,4) on the device (opt-in sampler, not the project Generator's stream)."""
+        self._check(self._lib.tq_sample_quartets_dev(self._h, int(seed) & (2**64 - 1), Q, d_ranks or None, d_quartets,
+                                                     stream or None))
 
     def unrank_dev(self, d_ranks: int, Q: int, d_quartets: int, stream: int = 0):
         self._check(self._lib.tq_unrank_dev(self._h, d_ranks, Q, d_quartets, stream or None))

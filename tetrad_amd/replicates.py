@@ -1,0 +1,161 @@
+"""Bootstrap replicates end to end on the GPUs: host-side mirror of the replicate loop of
+tetrad/src/run_inference.py:378-407 (minus the supertree step, which is out of scope).
+
+Per replicate the reference (1) resamples loci and rewrites the HDF5 database (:388-389,
+`resample_tmp_database` :99-143), (2) draws a fresh random quartet sample from the project Generator
+(`iter_chunks_random` :384 -- a generator, so its `rng.choice` runs at the first `next()` inside
+`distributor`, i.e. AFTER the three draws of the resampler), (3) resolves the chunks on the engines and
+collects the rows (:392).  Here:
+
+  * the draws stay on ONE NumPy Generator in exactly that order -- locus indices, two integer seeds, the
+    rank sample -- so the Generator state saved after replicate k (:405-407) is the reference's.  They do
+    not depend on any result, so a producer thread makes them several replicates ahead
+    (`ahead`), straight into page-locked buffers;
+  * the replicate is built on the device right behind the previous replicate's kernels
+    (`tq_bootstrap_async`: nothing but the locus indices crosses PCIe);
+  * the sample is unranked on the device and resolved by `ShardedResolver` (every rank its parts, one
+    all-gather per piece, rows to the destination rank's host arrays), two replicates in flight: the D2H of
+    replicate k runs under the kernels of replicate k+1.
+
+`sampler="device"` replaces the host's `rng.choice(C(T,4), Q, replace=False)` (about 30 ms for 1e6 of
+10.7e6 -- more than a replicate's kernels on one GPU, and the same on every rank) by the library's
+counter-based sampler (`tq_sample_quartets_dev`: same distribution, not the Generator's stream; the
+Generator then only provides one extra integer seed per replicate).  Opt-in, like the device bootstrap's
+own random streams it is documented as distribution-equal, not stream-identical.
+"""
+from __future__ import annotations
+
+import queue
+import threading
+import time
+from math import comb
+from typing import Callable, Optional
+
+import numpy as np
+
+from . import bootstrap
+from .distributor import ShardedResolver
+from .engine import QuartetEngine, pinned_empty
+
+
+class ReplicateRunner:
+    def __init__(self, engine: QuartetEngine, seqarr: np.ndarray, spans: np.ndarray, nquartets: int, *,
+                 seed=None, rng: Optional[np.random.Generator] = None, sampler: str = "host", group=None,
+                 pieces: Optional[int] = None, dst: Optional[int] = 0, ahead: int = 3):
+        import torch
+        if sampler not in ("host", "device"):
+            raise ValueError("sampler must be 'host' or 'device'")
+        self.torch = torch
+        self.engine = engine
+        self.sampler = sampler
+        self.rng = rng if rng is not None else np.random.default_rng(seed)
+        engine.set_source(seqarr, spans)
+        self.nloci = int(np.asarray(spans).reshape(-1, 2).shape[0])
+        self.T = int(seqarr.shape[0])
+        self.total = comb(self.T, 4)
+        self.Q = int(nquartets)
+        if self.Q > self.total:
+            raise ValueError(f"cannot sample {self.Q} of {self.total} quartets")
+        self.res = ShardedResolver(self.Q, engine=engine, group=group, pieces=pieces, dst=dst, nbuf=2)
+        self.n_local = self.res.n_local
+        self.ranges = self.res.ranges
+        self.dev = self.res.dev
+        self.ahead = max(1, int(ahead))
+        self._q: Optional[queue.Queue] = None
+        self._thread: Optional[threading.Thread] = None
+        self._stop = threading.Event()
+        self.rng_state_after: list = []          # Generator state after the draws of each consumed replicate
+        n = max(1, self.n_local)
+        self._d_ranks = torch.empty(n, dtype=torch.int64, device=self.dev)
+        self._d_all = torch.empty((self.Q, 4), dtype=torch.int32, device=self.dev) if sampler == "device" else None
+        self._local_index = torch.from_numpy(self.res.plan.local_index(self.res.rank)).to(self.dev) \
+            if sampler == "device" else None
+        self.res.d_q = torch.empty((n, 4), dtype=torch.int32, device=self.dev)
+
+    # -- the draws of one replicate, in the reference's order ---------------------------------------------
+    def _draw(self):
+        rng = self.rng
+        lidxs, s1, s2 = bootstrap.draw_replicate(self.nloci, rng)              # run_inference.py:117-123
+        if self.sampler == "host":
+            idx = rng.choice(self.total, size=self.Q, replace=False)           # combinations.py:113
+            local = pinned_empty(max(1, self.n_local), np.int64)
+            o = 0
+            for lo, hi in self.ranges:                                         # this rank's parts
+                local[o:o + hi - lo] = idx[lo:hi]
+                o += hi - lo
+            sample = local
+        else:
+            sample = int(rng.integers(2**63))                                   # one seed for the device sampler
+        return lidxs, s1, s2, sample, rng.bit_generator.state
+
+    def _producer(self, n: int):
+        for _ in range(n):
+            if self._stop.is_set():
+                break
+            t0 = time.perf_counter()
+            d = self._draw()
+            item = (d, (time.perf_counter() - t0) * 1e3)
+            while not self._stop.is_set():
+                try:
+                    self._q.put(item, timeout=0.1)
+                    break
+                except queue.Full:
+                    continue
+
+    # -- the loop -----------------------------------------------------------------------------------------
+    def run(self, nreps: int, subsample_snps: bool = True, on_result: Optional[Callable] = None) -> dict:
+        """`nreps` bootstrap replicates.  `on_result(k, S, rstat, rscor, flags)` is called on the destination
+        rank as each replicate's rows arrive (host arrays owned by the callee).  Returns timing / flag stats."""
+        torch, eng, res = self.torch, self.engine, self.res
+        self._stop.clear()
+        self._q = queue.Queue(maxsize=self.ahead)
+        self._thread = threading.Thread(target=self._producer, args=(nreps,), daemon=True)
+        self._thread.start()
+        cur = torch.cuda.current_stream(self.dev)
+        stats = dict(sites=[], host_ms=[], wait_ms=[], flags=dict(zero_data=0, degenerate=0, no_convergence=0))
+        pending = None
+
+        def collect(k, S, b):
+            rstat, rscor, flags = res.finish(b)
+            if flags is not None:
+                stats["flags"]["zero_data"] += int((flags & 1).sum())
+                stats["flags"]["degenerate"] += int(((flags & 2) != 0).sum())
+                stats["flags"]["no_convergence"] += int(((flags & 8) != 0).sum())
+                if on_result is not None:
+                    on_result(k, S, rstat, rscor, flags)
+
+        try:
+            for k in range(nreps):
+                t0 = time.perf_counter()
+                (lidxs, s1, s2, sample, state), draw_ms = self._q.get()
+                stats["wait_ms"].append((time.perf_counter() - t0) * 1e3)
+                stats["host_ms"].append(draw_ms)
+                self.rng_state_after.append(state)
+                S = eng.bootstrap(lidxs, s1, s2, stream=cur.cuda_stream)        # enqueued behind replicate k-1
+                stats["sites"].append(S)
+                if self.n_local:
+                    if self.sampler == "host":
+                        self._d_ranks.copy_(torch.from_numpy(sample), non_blocking=True)
+                        keep = sample                                           # alive until the copy has run
+                        eng.unrank_dev(self._d_ranks.data_ptr(), self.n_local, res.d_q.data_ptr(), cur.cuda_stream)
+                    else:
+                        keep = None
+                        eng.sample_quartets_dev(sample, self.Q, self._d_all.data_ptr(), 0, cur.cuda_stream)
+                        torch.index_select(self._d_all, 0, self._local_index, out=res.d_q)
+                b = k & 1
+                res.start(subsample_snps, b)
+                res.sets[b]["keep"] = keep
+                if pending is not None:
+                    collect(*pending)
+                pending = (k, S, b)
+            if pending is not None:
+                collect(*pending)
+        finally:
+            self._stop.set()
+            self._thread.join()
+        return stats
+
+    def close(self):
+        self._stop.set()
+        if self._thread is not None:
+            self._thread.join()

@@ -230,6 +230,16 @@ int tq_format_qmc(const uint32_t *quartets, const uint32_t *rstat, const double 
                   int weights, int64_t min_snps, double min_ratio, char *out, int64_t cap,
                   int64_t *written, int64_t *n_lines);
 
+/* Quartet supertree (host code, no device involved): weighted Quartet MaxCut over `n` resolved quartets
+ * splits u32[n,4] = "a,b|c,d" (the taxa of a wQMC input line, run_inference.py:264-305), weights f64[n] or
+ * NULL (all 1), taxa 0..ntaxa-1.  Writes the unrooted tree as newick with the taxon numbers as tip labels
+ * ("((0,1),(2,3),4);"), *written = its length (TQ_ERR_OOM with the needed size when cap is too small).
+ * Takes the place of: `bin/max-cut-tree qrtt=.. weights=on|off otre=..` as called by run_qmc
+ * (run_inference.py:146-166).  That binary ships without source and is never run or read here: this is an
+ * implementation from the published method, and parity with it is UNPINNED by construction.        */
+int tq_qmc_tree(const uint32_t *splits, const double *weights, int64_t n, int64_t ntaxa, uint64_t seed,
+                char *out, int64_t cap, int64_t *written);
+
 /* Device facts used by bench.py: writes CU count, wave slots used by the resolve
  * kernel per CU and the padded row pitch in bytes.                                 */
 int tq_device_info(tq_ctx *ctx, int32_t *num_cu, int32_t *waves_per_cu, int64_t *row_pitch);

@@ -1,0 +1,173 @@
+"""Clean-room weighted Quartet MaxCut (tq_qmc_tree, host C++).  PARITY UNPINNED: the reference delegates this step
+to a prebuilt binary without source (run_inference.py:146-166), holds no expected tree for any quartet set, and the
+binary may not be run.  Tested here: what any correct implementation must do -- recover the generating tree from
+its own quartets (complete, sampled, noisy + weighted), determinism, malformed input."""
+from itertools import combinations
+
+import numpy as np
+import pytest
+
+from tetrad_amd import qmc, synth
+
+
+def _tree_dist(children, root, T):
+    """pairwise path lengths (unit edges) between the tips of a rooted binary tree given as children[node]."""
+    parent = {}
+    for p, (a, b) in children.items():
+        parent[a] = p
+        parent[b] = p
+    def path(t):
+        out = [t]
+        while out[-1] in parent:
+            out.append(parent[out[-1]])
+        return out
+    paths = [path(t) for t in range(T)]
+    D = np.zeros((T, T), int)
+    for i in range(T):
+        pi = {n: k for k, n in enumerate(paths[i])}
+        for j in range(i + 1, T):
+            for k, n in enumerate(paths[j]):
+                if n in pi:
+                    D[i, j] = D[j, i] = k + pi[n]
+                    break
+    return D
+
+
+def _true_splits(D, quartets):
+    """the split of each quartet on the tree: the pairing with the smallest sum of path lengths (four-point condition)"""
+    out = np.empty_like(quartets)
+    for i, (a, b, c, d) in enumerate(quartets):
+        s = [D[a, b] + D[c, d], D[a, c] + D[b, d], D[a, d] + D[b, c]]
+        k = int(np.argmin(s))
+        out[i] = [(a, b, c, d), (a, c, b, d), (a, d, b, c)][k]
+    return out
+
+
+def _bipartitions_from_children(children, root, T):
+    below = {}
+    def rec(n):
+        if n < T:
+            below[n] = frozenset([n])
+        else:
+            a, b = children[n]
+            below[n] = rec(a) | rec(b)
+        return below[n]
+    rec(root)
+    allt = frozenset(range(T))
+    return {min(s, allt - s, key=lambda x: (len(x), sorted(x))) for s in below.values() if 1 < len(s) < T - 1}
+
+
+def _bipartitions_from_newick(nwk, T):
+    assert nwk.endswith(";")
+    pos = 0
+    splits = []
+    def parse():
+        nonlocal pos
+        if nwk[pos] == "(":
+            pos += 1
+            s = frozenset()
+            while True:
+                s |= parse()
+                if nwk[pos] == ",":
+                    pos += 1
+                    continue
+                assert nwk[pos] == ")"
+                pos += 1
+                break
+            splits.append(s)
+            return s
+        j = pos
+        while nwk[j].isdigit():
+            j += 1
+        t = int(nwk[pos:j])
+        pos = j
+        return frozenset([t])
+    top = parse()
+    assert nwk[pos] == ";" and top == frozenset(range(T)), "every taxon exactly once"
+    allt = frozenset(range(T))
+    return {min(s, allt - s, key=lambda x: (len(x), sorted(x))) for s in splits if 1 < len(s) < T - 1}
+
+
+@pytest.mark.parametrize("T,seed", [(5, 1), (8, 2), (13, 3), (24, 4), (40, 5)])
+def test_recovers_the_generating_tree_from_all_its_quartets(T, seed):
+    rng = np.random.default_rng(seed)
+    children, root = synth.random_tree_children(T, rng)
+    D = _tree_dist(children, root, T)
+    quartets = np.array(list(combinations(range(T), 4)), np.uint32)
+    splits = _true_splits(D, quartets)
+    nwk = qmc.qmc_tree(splits, None, T, seed=7)
+    assert _bipartitions_from_newick(nwk, T) == _bipartitions_from_children(children, root, T)
+    assert qmc.qmc_tree(splits, None, T, seed=7) == nwk                     # deterministic in the seed
+    # row order does not matter (the reference has to shuffle its input file, run_inference.py:323-327)
+    perm = rng.permutation(len(splits))
+    assert _bipartitions_from_newick(qmc.qmc_tree(splits[perm], None, T, seed=7), T) == _bipartitions_from_newick(nwk, T)
+
+
+def test_recovers_the_tree_from_a_random_sample_of_quartets():
+    """the reference's recommended sampling: >= nsamples**2.8 quartets (write_database.py:85)"""
+    T = 30
+    rng = np.random.default_rng(11)
+    children, root = synth.random_tree_children(T, rng)
+    D = _tree_dist(children, root, T)
+    quartets = synth.random_quartets(T, int(T ** 2.8), seed=3)
+    nwk = qmc.qmc_tree(_true_splits(D, quartets), None, T, seed=1)
+    assert _bipartitions_from_newick(nwk, T) == _bipartitions_from_children(children, root, T)
+
+
+def test_weights_outvote_noise():
+    """20 % of the quartets wrong but light, the correct ones heavy: weighted -> the true tree; and the unweighted run
+    on the same rows still finds most of it."""
+    T = 16
+    rng = np.random.default_rng(21)
+    children, root = synth.random_tree_children(T, rng)
+    D = _tree_dist(children, root, T)
+    quartets = np.array(list(combinations(range(T), 4)), np.uint32)
+    splits = _true_splits(D, quartets)
+    wrong = rng.random(len(splits)) < 0.2
+    noisy = splits.copy()
+    noisy[wrong] = noisy[wrong][:, [0, 2, 1, 3]]                            # a,c|b,d instead of a,b|c,d
+    w = np.where(wrong, 0.05, 1.0)
+    truth = _bipartitions_from_children(children, root, T)
+    assert _bipartitions_from_newick(qmc.qmc_tree(noisy, w, T), T) == truth
+    got = _bipartitions_from_newick(qmc.qmc_tree(noisy, None, T), T)
+    assert len(got & truth) >= len(truth) - 2
+
+
+def test_degenerate_inputs():
+    assert qmc.qmc_tree(np.zeros((0, 4), np.uint32), None, 1) == "0;"
+    assert _bipartitions_from_newick(qmc.qmc_tree(np.zeros((0, 4), np.uint32), None, 6), 6) == set()    # a star
+    one = np.array([[0, 1, 2, 3]], np.uint32)
+    assert _bipartitions_from_newick(qmc.qmc_tree(one, None, 4), 4) == {frozenset([0, 1])}
+    # taxa no quartet mentions still appear exactly once; repeated taxa inside a row are ignored
+    rows = np.array([[0, 1, 2, 3], [0, 1, 2, 2], [0, 1, 2, 3]], np.uint32)
+    bips = _bipartitions_from_newick(qmc.qmc_tree(rows, np.array([1.0, 5.0, 1.0]), 7), 7)
+    allt = frozenset(range(7))
+    # the one informative quartet 0,1|2,3 is displayed: some edge has 0,1 on one side and 2,3 on the other
+    assert any(({0, 1} <= s and not ({2, 3} & s)) or ({0, 1} <= allt - s and not ({2, 3} & (allt - s))) for s in bips)
+    from tetrad_amd._lib import TetradHipError
+    with pytest.raises(TetradHipError):
+        qmc.qmc_tree(np.array([[0, 1, 2, 9]], np.uint32), None, 4)         # taxon >= ntaxa
+
+
+def test_file_mirror_and_array_entry(tmp_path):
+    """run_qmc(in, out, use_weights) on a wQMC file; infer_supertree_from_arrays straight from a result triple."""
+    T = 10
+    rng = np.random.default_rng(5)
+    children, root = synth.random_tree_children(T, rng)
+    D = _tree_dist(children, root, T)
+    quartets = np.array(list(combinations(range(T), 4)), np.uint32)
+    splits = _true_splits(D, quartets)
+    f = tmp_path / "qmc_in.txt"
+    f.write_text("".join("%d,%d|%d,%d:%.5f\n" % (*r, 1.0) for r in splits.tolist()))
+    qmc.run_qmc(f, tmp_path / "out.nwk", True, ntaxa=T)
+    truth = _bipartitions_from_children(children, root, T)
+    assert _bipartitions_from_newick((tmp_path / "out.nwk").read_text().strip(), T) == truth
+    # a result triple whose topology column encodes the true split of each (sorted) quartet
+    topo = np.array([[tuple(s) == (a, b, c, d), tuple(s) == (a, c, b, d), tuple(s) == (a, d, b, c)].index(True)
+                     for s, (a, b, c, d) in zip(splits.tolist(), quartets.tolist())], np.uint32)
+    rstat = np.stack([topo, np.full(len(topo), 100, np.uint32)], axis=1)
+    rscor = np.full((len(topo), 3), 5.0)
+    rscor[np.arange(len(topo)), topo] = 1.0
+    for weights in (0, 1, 2, 3):
+        nwk = qmc.infer_supertree_from_arrays(quartets, rscor, rstat, T, weights=weights)
+        assert _bipartitions_from_newick(nwk, T) == truth

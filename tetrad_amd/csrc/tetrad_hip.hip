@@ -41,6 +41,7 @@
 #include <mutex>
 #include <new>
 #include <string>
+#include <unordered_map>
 #include <unordered_set>
 #include <vector>
 
@@ -55,6 +56,7 @@ namespace {
 #include "hqr.hpp"
 #include "bootstrap.hpp"
 #include "format.hpp"
+#include "qmc.hpp"
 
 }  // namespace
 
@@ -1467,6 +1469,25 @@ int tq_format_qmc(const uint32_t *quartets, const uint32_t *rstat, const double 
     const int64_t n = format_qmc(quartets, rstat, rscor, Q, weights, min_snps, min_ratio, out, cap, n_lines);
     *written = n < 0 ? -n : n;
     return n < 0 ? TQ_ERR_OOM : TQ_OK;
+}
+
+int tq_qmc_tree(const uint32_t *splits, const double *weights, int64_t n, int64_t ntaxa, uint64_t seed, char *out,
+                int64_t cap, int64_t *written)
+{
+    if (n < 0 || cap < 0 || !written || ntaxa < 1 || ntaxa > (1 << 24) || (n > 0 && !splits) || (cap > 0 && !out))
+        return TQ_ERR_INVALID_ARG;
+    try {
+        std::string nwk;
+        const int rc = qmc_tree(splits, weights, n, ntaxa, seed, nwk);
+        if (rc) return rc;
+        *written = (int64_t)nwk.size();
+        if ((int64_t)nwk.size() > cap) return TQ_ERR_OOM;
+        memcpy(out, nwk.data(), nwk.size());
+        return TQ_OK;
+    } catch (const std::bad_alloc &) {
+        *written = 0;
+        return TQ_ERR_OOM;
+    }
 }
 
 int tq_device_info(tq_ctx *ctx, int32_t *num_cu, int32_t *waves_per_cu, int64_t *row_pitch)

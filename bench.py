@@ -206,6 +206,9 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo = rehearsal of the N>1 control flow on a box with fewer GPUs than ranks")
     ap.add_argument("--pieces", type=int, default=0, help="N > 1: result pieces per batch (0 = automatic)")
+    ap.add_argument("--sharded", action="store_true",
+                    help="take the N > 1 code path (process group, all-gather per piece, regrouping, verification) "
+                         "even with one rank: a one-GPU rehearsal of the RCCL path when launched through torch.distributed.run")
     ap.add_argument("--sampler", default="host", choices=["host", "device"],
                     help="c5: quartet sample drawn on the project Generator (reference stream) or on the device")
     ap.add_argument("--svd-chunk", type=int, default=0)
@@ -227,14 +230,15 @@ def main():
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     dist = None
-    if world > 1:
+    multi = world > 1 or (args.sharded and "RANK" in os.environ)
+    if multi:
         import torch.distributed as dist
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group("gloo")
 
-    cfg = args.config or ("c3" if world == 1 else ("c3" if args.weak else "c4"))
+    cfg = args.config or ("c3" if not multi else ("c3" if args.weak else "c4"))
     if args.weak and cfg != "c3":
         raise SystemExit("--weak is the c3 shape")
     sub = not args.full
@@ -266,12 +270,12 @@ def main():
     stream = torch.cuda.current_stream().cuda_stream
 
     def barrier():
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize()
 
     extra = {}
-    if world == 1:
+    if not multi:
         d_r = torch.from_numpy(ranks_all).to(dev)
         d_q = torch.empty((Q, 4), dtype=torch.int32, device=dev)
         eng.unrank_dev(d_r.data_ptr(), Q, d_q.data_ptr(), stream)
@@ -285,7 +289,8 @@ def main():
             return out
     else:
         from tetrad_amd.distributor import ShardedResolver
-        res = ShardedResolver(Q, engine=eng, device=dev_index, dst=0, pieces=args.pieces or None)
+        res = ShardedResolver(Q, engine=eng, device=dev_index, dst=0, pieces=args.pieces or None,
+                              collective_always=True)
         res.set_ranks(ranks_all)
         torch.cuda.synchronize()
         last = [None]
@@ -318,7 +323,7 @@ def main():
     kms_serial, launches_serial = eng.timing_read_kernels()
     eng.set_option("svd_streams", 0)
     eng.timing_enable(False)
-    if world > 1:
+    if multi:
         gdev = dev if args.backend == "nccl" else torch.device("cpu")
         t = torch.tensor([elapsed], dtype=torch.float64, device=gdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -326,7 +331,7 @@ def main():
     step()                                  # results of the default configuration
 
     rstat, rscor, flags = results()
-    if world == 1:
+    if not multi:
         # device-resident rate (no result D2H) and the PCIe-inclusive rate of the host-buffer API (quartets
         # H2D from a page-locked array + results D2H per call); reported beside `value`, never as `value`
         quartets_h = pinned_empty((Q, 4), np.uint32)
@@ -394,32 +399,32 @@ def main():
         ms_per_step = elapsed / args.steps * 1e3
         value = Q * args.steps / elapsed
         A = 4 * S + 48                                   # algorithmic bytes per quartet
-        q_rank = res.n_local if world > 1 else Q           # quartets one launch of the scan kernel covers here
+        q_rank = res.n_local if multi else Q               # quartets one launch of the scan kernel covers here
         bytes_per_launch = q_rank * A + 4 * S
         per_pass = {k: v / max(1, launches) for k, v in kms.items()}
         dominant_ms = per_pass["scan"]
         achieved = bytes_per_launch / (dominant_ms / 1e3) / 1e9
         traffic, traffic_src = None, "not measured in this run"
         tf = REPO / "profiles" / f"traffic_{cfg}_{'sub' if sub else 'full'}.json"
-        if tf.exists() and world == 1 and not args.quartets:
+        if tf.exists() and not multi and not args.quartets:
             tj = json.loads(tf.read_text())
             traffic = tj.get("hbm_bytes_per_launch")
             traffic_src = (f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, collated in {tf.name} "
                            f"(commit {tj.get('commit', 'unknown')}); not re-measured in this run")
         what = ("lexicographic (all)" if lexi else "random")
         workload = (f"{cfg}: {T} taxa x {S} SNPs, {Q} {what} quartets"
-                    + (f" in one batch cut over {world} GPUs (strong scaling)" if world > 1 and not args.weak else "")
+                    + (f" in one batch cut over {world} GPUs (strong scaling)" if multi and not args.weak else "")
                     + (f" = {Q // world} per GPU (weak scaling)" if args.weak else "")
                     + f", subsample_snps={sub}, results delivered to host arrays inside the step")
         line = {
             "metric": "resolved quartets/sec (whole node)", "value": value, "unit": "quartets/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
-            "higher_is_better": True, "scaling": "weak" if (args.weak or world == 1) else "strong",
+            "higher_is_better": True, "scaling": "weak" if (args.weak or not multi) else "strong",
             "vs_baseline": None,
             "dtype": "u8 scan / u32 counts / f64 SVD", "data": "synthetic",
             "config": {"workload": workload, "quartets": Q, "taxa": T, "snps": S, "subsample_snps": sub,
                        "parallelism": (f"quartet-sharded x{world}, one all-gather per result piece, rows to rank 0's host"
-                                       if world > 1 else "one GPU, result D2H overlapped inside tq_resolve_to_host")},
+                                       if multi else "one GPU, result D2H overlapped inside tq_resolve_to_host")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
                          "note": ("algorithmic bytes (SURVEY 8d: 4*S+48 per quartet) over the dominant kernel's time; the "
@@ -442,14 +447,14 @@ def main():
         line.update(extra)
         if args.phases in (1, 2):
             line["INVALID_diagnostic_phases"] = args.phases
-        if not args.no_cpu and args.phases in (0, 3) and world == 1:     # CPU leg: rank 0 at N=1 only
+        if not args.no_cpu and args.phases in (0, 3) and not multi:      # CPU leg: rank 0 at N=1 only
             quartets_np = np.array(quartets_h)
             cb, parity = cpu_baseline(tmparr, tmpmap, quartets_np, sub, rstat, rscor)
             line["cpu_baseline"] = cb
             line["parity_on_cpu_sample"] = parity
             line["gpu_over_cpu"] = value / cb["value"]
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if multi:
         dist.barrier()
         dist.destroy_process_group()
 

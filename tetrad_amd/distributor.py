@@ -14,7 +14,7 @@ MI355X-native scheme of SURVEY.md section 8e:
     per piece, the gathered parts are regrouped into global order on the device and copied to the
     destination rank's host arrays -- all of that under the kernels of the next piece.  A replicate
     of up to ~3e5 quartets per rank is a single piece = one collective per replicate; large batches
-    use up to 8 pieces of >= 32k quartets per rank so that only the last piece's gather + D2H is
+    use up to 8 pieces of >= 131k quartets per rank so that only the last piece's gather + D2H is
     exposed.
 
 The per-rank compute step is injectable so that the partition / gather / regroup logic is
@@ -28,7 +28,8 @@ from typing import Callable, Iterable, Optional
 
 import numpy as np
 
-MIN_PART_ROWS = 32768          # a rank's part of a piece is at least this many quartets (keeps the GPU filled)
+MIN_PART_ROWS = 131072         # a rank's part of a piece is at least this many quartets: the singular-value kernels of a
+                               # part then make >= 3 rounds over the chip (a wave per 64 matrices), so their tails stay small
 MAX_PIECES = 8
 
 
@@ -117,7 +118,7 @@ class ShardedResolver:
     """
 
     def __init__(self, Q: int, *, engine=None, compute: Optional[Callable] = None, group=None, device=None,
-                 pieces: Optional[int] = None, dst: Optional[int] = None, nbuf: int = 1):
+                 pieces: Optional[int] = None, dst: Optional[int] = None, nbuf: int = 1, collective_always: bool = False):
         import torch
         import torch.distributed as dist
         if (engine is None) == (compute is None):
@@ -129,6 +130,9 @@ class ShardedResolver:
         else:
             self.world, self.rank, self.backend = 1, 0, None
         self.engine, self.compute, self.dst = engine, compute, dst
+        # a process group of ONE rank normally skips the collective; `collective_always` issues it anyway (a
+        # one-GPU rehearsal of the RCCL code path: communicator set-up, uint8 all-gather, stream hand-over)
+        self.collective = self.world > 1 or (collective_always and self.backend is not None)
         self.plan = ShardPlan(Q, self.world, pieces)
         self.Q = int(Q)
         self.ranges = self.plan.local_ranges(self.rank)
@@ -140,7 +144,7 @@ class ShardedResolver:
         else:
             self.dev = torch.device("cpu")
         # where the collective runs: on the GPUs with RCCL, on the host with gloo
-        self.gdev = self.dev if (self.backend == "nccl" or self.world == 1) else torch.device("cpu")
+        self.gdev = self.dev if (self.backend == "nccl" or not self.collective) else torch.device("cpu")
         self.on_gpu = self.gdev.type == "cuda"
         P = self.plan
         self.sets = []
@@ -148,7 +152,7 @@ class ShardedResolver:
             s = dict(
                 slabs=[torch.zeros(P.slab_bytes(i), dtype=torch.uint8, device=self.dev) for i in range(P.npieces)],
                 gathered=[torch.zeros(self.world * P.slab_bytes(i), dtype=torch.uint8, device=self.gdev)
-                          if self.world > 1 else None for i in range(P.npieces)],
+                          if self.collective else None for i in range(P.npieces)],
                 # the whole batch in global order (every rank holds it after the gathers)
                 all_rstat=torch.zeros(P.rows_padded * 8, dtype=torch.uint8, device=self.gdev),
                 all_rscor=torch.zeros(P.rows_padded * 24, dtype=torch.uint8, device=self.gdev),
@@ -230,7 +234,7 @@ class ShardedResolver:
                 sl[32 * p:32 * p + n] = np.asarray(flags[off:off + n], dtype=np.uint8)
             # ONE collective per piece: every rank receives the parts of all ranks
             work = None
-            if self.world > 1:
+            if self.collective:
                 src = slab if slab.device == self.gdev else slab.cpu()        # gloo rehearsal with the engine
                 work = dist.all_gather_into_tensor(s["gathered"][i], src, group=self.group, async_op=True)
                 g = s["gathered"][i].view(self.world, blk)
@@ -256,7 +260,7 @@ class ShardedResolver:
                 with torch.cuda.stream(self.side):
                     regroup_and_copy()
             else:
-                if self.engine is not None and self.world == 1:
+                if self.engine is not None and not self.collective:
                     torch.cuda.synchronize(self.dev)
                 regroup_and_copy()
         if self.on_gpu:

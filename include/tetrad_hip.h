@@ -203,7 +203,8 @@ int tq_timing_read_kernels(tq_ctx *ctx, double *ms, int n_ms, int64_t *calls);
  * 1 Householder+QR), xcd_remap (1: scan workgroups of one XCD take a contiguous part of the sorted order),
  * svd_wpc (blocks per CU of the singular-value grids, 0 = one pass per block), svd_chunk (quartets per
  * pass of the singular-value stage = per result-copy piece, default 2^18), svd_streams (1 or 2: chunks alternate
- * between two streams so that one chunk's tail is filled by the next chunk; default 2), bdsqr_maxit (QR sweeps per
+ * between two streams so that one chunk's tail is filled by the next chunk; default 2), share_c (1: scan variant that also shares row c inside a
+ * workgroup; measured slower, off), bdsqr_maxit (QR sweeps per
  * singular value before TQ_FLAG_NO_CONVERGENCE, default 60), phases (timing diagnostics).         */
 int tq_set_option(tq_ctx *ctx, const char *name, int64_t value);
 

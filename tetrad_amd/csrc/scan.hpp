@@ -324,14 +324,25 @@ __device__ __forceinline__ void cd_pair(uint32_t cw, uint32_t dw, uint32_t &lo, 
 // LDS image of the shared part of one step: abp = pattern partial ((a<<2)+b)<<4 as 2 x 64 uint4
 // panels (sites 0-15 / 16-31 of every lane), then the plane records of a and of b (64 uint4 each)
 constexpr int SHARED_SLOTS = 208;
+// SHC ("share row c"): when every quartet of a block has the leader's (a,b,c) -- the normal case for
+// lexicographic enumerations, combinations.py:40-55, and frequent in an (a,b,c)-sorted random sample -- one more
+// job fetches the nibble codes (x4 copy) and the plane record of row c once per workgroup and step into two more
+// panels of the image (slots 208-271, 272-335); the waves then read their row c from LDS and stream only row d
+// from the L2: 2.6 KiB instead of 4.4 KiB per quartet-step through the L2 -> CU path.
+// MEASURED SLOWER (profiles/r02_*/share_c_ab.txt): c2 lexicographic, where every block qualifies, 1.75 -> 2.13 ms;
+// c3 random 6.7 -> 8.3 ms.  Two more LDS reads per wave-step on an LDS pipe that is ~80 % busy, 85 instead of 72
+// VGPRs and 24 instead of 20 KiB of LDS (6 instead of 7 workgroups per CU) cost more than the 40 % fewer bytes from
+// L2 save: the kernel is not bound by bytes.  Off by default (option "share_c"), parity-tested.
+constexpr int SHARED_SLOTS_C = SHARED_SLOTS + 128;
 
-template <bool SUB, int METHOD, int NW>
+template <bool SUB, int METHOD, int NW, bool SHC = false>
 __global__ void __launch_bounds__(NW *WAVE)
 tq_scan_wg_kernel(DevData d, const uint32_t *__restrict__ quartets, const uint32_t *__restrict__ order, int64_t Q,
                   uint32_t *__restrict__ cm, int64_t xcd_chunk)
 {
     static_assert(NW >= 1 && NW <= 16, "waves per workgroup");
-    __shared__ uint4 shared_ab[2][SHARED_SLOTS];
+    static_assert(!SHC || NW >= 4, "the row-c job needs a fourth wave");
+    __shared__ uint4 shared_ab[2][SHC ? SHARED_SLOTS_C : SHARED_SLOTS];
     __shared__ uint32_t hist_all[NW][256];
     __shared__ uint32_t park_all[NW][WAVE * PAT_STRIDE / 4];
     const int tid = threadIdx.x;
@@ -354,7 +365,8 @@ tq_scan_wg_kernel(DevData d, const uint32_t *__restrict__ quartets, const uint32
     // cooperative jobs per step: 0,1 = nibble codes of rows a (x4 copy) and b for sites 0-15 / 16-31
     // of every lane -> abp panels 0,1; 2 = plane records of a and b (+ run-begin bits) -> r1, B.
     // Wave w takes the jobs j with j % NW == w.
-    constexpr int NJOB = 3, JPW = (NJOB + NW - 1) / NW;        // jobs per wave
+    // With SHC: 3 = nibble codes (x4 copy) and plane record of the block's common row c.
+    constexpr int NJOB = SHC ? 4 : 3, JPW = (NJOB + NW - 1) / NW;        // jobs per wave
     __syncthreads();
 
     const int64_t nslot = xcd_chunk > 0 ? 8 * xcd_chunk : nblk;
@@ -375,6 +387,23 @@ tq_scan_wg_kernel(DevData d, const uint32_t *__restrict__ quartets, const uint32
         uint32_t la = __builtin_amdgcn_readfirstlane(lq.x), lb = __builtin_amdgcn_readfirstlane(lq.y);
         const bool leader_ok = (la < T) & (lb < T);
         if (!leader_ok) la = lb = 0;
+        // every wave looks at all NW quartets of the block, so all of them reach the same verdict without
+        // talking to each other: do they all have the leader's (a,b,c)?
+        bool shc = false;
+        uint32_t lc = 0;
+        if (SHC) {
+            lc = __builtin_amdgcn_readfirstlane(lq.z);
+            shc = leader_ok && lc < T && it0 + NW <= Q;
+#pragma unroll
+            for (int k = 1; k < NW; ++k) {
+                const int64_t itk = min(it0 + k, Q - 1);
+                const int64_t qk = order ? (int64_t)order[itk] : itk;
+                const uint4 v = reinterpret_cast<const uint4 *>(quartets)[qk];
+                shc = shc && __builtin_amdgcn_readfirstlane(v.x) == la && __builtin_amdgcn_readfirstlane(v.y) == lb &&
+                      __builtin_amdgcn_readfirstlane(v.z) == lc && __builtin_amdgcn_readfirstlane(v.w) < T;
+            }
+            if (!shc) lc = 0;
+        }
         // this wave's quartet
         const int64_t it = it0 + w;
         const bool have = it < Q;
@@ -409,10 +438,12 @@ tq_scan_wg_kernel(DevData d, const uint32_t *__restrict__ quartets, const uint32
                 r.w = *reinterpret_cast<const uint32_t *>(runbeg + (uint32_t)lane * 4u + (uint32_t)tile * (WAVE * 4));
                 return r;
             }
+            if (SHC && job == 3 && shc) return ld16(nib4, lc * npitch + (uint32_t)lane * 16u + (uint32_t)tile * (TILE / 2));
             return make_uint4(0, 0, 0, 0);
         };
         auto fetch_y = [=](int job, int tile) -> uint4 {
             if (job == 2) return ld12(planes3, lb * w3pitch + (uint32_t)lane * 12u + (uint32_t)tile * (WAVE * 12));
+            if (SHC && job == 3 && shc) return ld12(planes3, lc * w3pitch + (uint32_t)lane * 12u + (uint32_t)tile * (WAVE * 12));
             return make_uint4(0, 0, 0, 0);
         };
         // what goes into the LDS image of one step (uint4 slots): abp panels 0-63 / 64-127 =
@@ -425,6 +456,19 @@ tq_scan_wg_kernel(DevData d, const uint32_t *__restrict__ quartets, const uint32
             } else if (job == 2) {
                 buf[128 + lane] = make_uint4(x.y, x.z, x.x | y.x, (x.y ^ y.y) | (x.z ^ y.z));
                 reinterpret_cast<uint32_t *>(buf + 192)[lane] = x.w;
+            } else if (SHC && job == 3 && shc) {
+                buf[SHARED_SLOTS + lane] = x;                  // nibble codes of row c, pre-multiplied by 4
+                buf[SHARED_SLOTS + 64 + lane] = y;             // its plane record {miss, p0, p1, 0}
+            }
+        };
+        // a wave's own rows: c and d, or d alone when row c comes through the image
+        auto load_mine = [=](OwnRegs &r, int tile) {
+            if (SHC && shc) {
+                const uint32_t tn = (uint32_t)tile * (TILE / 2), tp = (uint32_t)tile * (WAVE * 12);
+                r.d = ld16(nib, oo.d + tn);
+                r.pd = ld12(planes3, oo.pd + tp);
+            } else {
+                load_own(r, nib, nib4, planes3, oo, tile);
             }
         };
 
@@ -436,7 +480,7 @@ tq_scan_wg_kernel(DevData d, const uint32_t *__restrict__ quartets, const uint32
             sy[i] = fetch_y(job_of(i), 0);
         }
         OwnRegs A;
-        load_own(A, nib, nib4, planes3, oo, 0);
+        load_mine(A, 0);
 #pragma unroll
         for (int i = 0; i < JPW; ++i) publish(shared_ab[0], job_of(i), sx[i], sy[i]);
         uint32_t tile_carry = 0;
@@ -452,6 +496,10 @@ tq_scan_wg_kernel(DevData d, const uint32_t *__restrict__ quartets, const uint32
                 ab1 = buf[64 + lane];
                 r1 = buf[128 + lane];
                 Bw = reinterpret_cast<const uint32_t *>(buf + 192)[lane];
+                if (SHC && shc) {
+                    own.c = buf[SHARED_SLOTS + lane];
+                    own.pc = buf[SHARED_SLOTS + 64 + lane];
+                }
             } else {                                        // group boundary: private rows a and b
                 const uint32_t o0 = q[0] * pitch + (uint32_t)t * TILE + (uint32_t)lane * 16u;
                 const uint32_t o1 = q[1] * pitch + (uint32_t)t * TILE + (uint32_t)lane * 16u;
@@ -480,7 +528,7 @@ tq_scan_wg_kernel(DevData d, const uint32_t *__restrict__ quartets, const uint32
             pat[4] = and_or(s2, m, ab1.x); pat[5] = and_or(s2 >> 4, m, ab1.y);
             pat[6] = and_or(s3, m, ab1.z); pat[7] = and_or(s3 >> 4, m, ab1.w);
             hist_patterns<1, METHOD == 3 ? 1 : METHOD>(pat, C, hist, park, [&]() {
-                load_own(own, nib, nib4, planes3, oo, tnext);
+                load_mine(own, tnext);
                 __builtin_amdgcn_sched_barrier(0);
             });
         };

@@ -117,6 +117,8 @@ struct tq_ctx {
     int bdsqr_maxit = 60;           // QR sweeps per singular value before a matrix is declared not converged
     int scan_wg = 4;                // waves per workgroup of the cooperative scan kernel (1 = one wave per quartet)
     int xcd_remap = 1;              // 1: scan workgroups of one XCD take a contiguous part of the sorted order
+    int share_c = 0;                // 1: scan kernel variant that also shares row c inside a workgroup (scan.hpp: SHC;
+                                    // measured slower everywhere -- the kernel is LDS/VALU-bound, not byte-bound -- kept as an A/B option)
     int svd_wpc = 0;                // blocks per CU of the bidiag / bdsqr grids (0 = one pass per block)
     // what tq_scan_dev left in the count slab (consumed by tq_svd_dev)
     const uint32_t *scanned_q = nullptr;
@@ -436,10 +438,10 @@ int launch_scan(tq_ctx *ctx, const uint32_t *dq, const uint32_t *order, int64_t 
     return TQ_OK;
 }
 
-template <bool SUB, int METHOD, int NW>
+template <bool SUB, int METHOD, int NW, bool SHC = false>
 int launch_scan_wg(tq_ctx *ctx, const uint32_t *dq, const uint32_t *order, int64_t Q, hipStream_t stream)
 {
-    auto kern = tq_scan_wg_kernel<SUB, METHOD, NW>;
+    auto kern = tq_scan_wg_kernel<SUB, METHOD, NW, SHC>;
     const int wgs = ctx->waves_per_cu > 0 ? (ctx->waves_per_cu + NW - 1) / NW : 0;
     // default: one block of NW quartets per workgroup, dispatched in sorted order.  Workgroups that
     // run at the same time are then neighbours of the (a,b) order (their shared rows are L2 hits) and
@@ -477,6 +479,13 @@ int launch_scan_n(tq_ctx *ctx, const uint32_t *dq, const uint32_t *order, int64_
                  : launch_scan_wg<false, 0, NW>(ctx, dq, order, Q, stream);                              \
     }
         TQ_WG_CASE(2)
+        if (ctx->scan_wg == 4 && ctx->share_c && m <= 1) {
+            if (subsample)
+                return m ? launch_scan_wg<true, 1, 4, true>(ctx, dq, order, Q, stream)
+                         : launch_scan_wg<true, 0, 4, true>(ctx, dq, order, Q, stream);
+            return m ? launch_scan_wg<false, 1, 4, true>(ctx, dq, order, Q, stream)
+                     : launch_scan_wg<false, 0, 4, true>(ctx, dq, order, Q, stream);
+        }
         TQ_WG_CASE(4)
         TQ_WG_CASE(16)
         TQ_WG_CASE(8)
@@ -1185,6 +1194,10 @@ int tq_set_option(tq_ctx *ctx, const char *name, int64_t value)
     }
     if (!strcmp(name, "xcd_remap")) {
         ctx->xcd_remap = value != 0;
+        return TQ_OK;
+    }
+    if (!strcmp(name, "share_c")) {
+        ctx->share_c = value != 0;
         return TQ_OK;
     }
     if (!strcmp(name, "svd_wpc")) {

@@ -346,7 +346,8 @@ def main():
             eng.resolve_dev(d_q.data_ptr(), Q, sub, d_rstat.data_ptr(), d_rscor.data_ptr(), d_flags.data_ptr(), stream)
         torch.cuda.synchronize()
         extra["device_resident_value"] = 3 * Q / (time.perf_counter() - t1)
-        eng.resolve(quartets_h, sub)
+        r_h = eng.resolve(quartets_h, sub)     # two warm calls: the pool then holds both sets of result arrays that
+        r_h = eng.resolve(quartets_h, sub)     # are alive at a time (pinning fresh pages costs milliseconds)
         t1 = time.perf_counter()
         for _ in range(3):
             r_h = eng.resolve(quartets_h, sub)

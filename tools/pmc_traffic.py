@@ -55,6 +55,7 @@ def main():
     ap.add_argument("--config", default="c3 sub, 1e6 quartets per launch")
     ap.add_argument("--out", type=Path, required=True)
     ap.add_argument("--copy-to", type=Path, default=None, help="directory that receives the two csv files")
+    ap.add_argument("--commit", default="", help="commit the profiled library was built from")
     args = ap.parse_args()
     ft, fc, ff = collect(args.fetch_dir, "FETCH_SIZE")
     wt, wc, wf = collect(args.write_dir, "WRITE_SIZE")
@@ -67,6 +68,7 @@ def main():
     write_kb = sum(wt.get(g, 0.0) for g in hot) / args.passes
     out = {
         "config": args.config,
+        "commit": args.commit or "unknown",
         "passes": args.passes,
         "fetch_size_kb_per_pass": fetch_kb,
         "write_size_kb_per_pass": write_kb,

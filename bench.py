@@ -155,12 +155,15 @@ def kernel_rooflines(kms: dict, calls: int, Q: int, S: int, sub: bool, cfg: str)
                         peak=F64_VECTOR_PEAK_TFLOPS, unit="TFLOP/s", frac=ach / F64_VECTOR_PEAK_TFLOPS,
                         model="(8/3)*16^3 useful flop per matrix"))
     if per.get("bdsqr", 0) > 0:
-        steps_per_matrix = {"c3": 226.0}.get(cfg, 226.0)
+        # measured with the kernel's counting mode (tools/bdsqr_stats.py, profiles/r02_pipeline/bdsqr_work.txt)
+        steps_per_matrix = {"c2": 235.4, "c3": 226.6, "c4": 221.1}.get(cfg, 226.6) if sub else \
+            {"c2": 229.0, "c3": 220.6, "c4": 215.6}.get(cfg, 220.6)
         fl = 3 * Q * steps_per_matrix * 26
         ach = fl / (per["bdsqr"] / 1e3) / 1e12
         out.append(dict(name="tq_bdsqr_kernel", ms=per["bdsqr"], bound="f64 valu", achieved=ach,
                         peak=F64_VECTOR_PEAK_TFLOPS, unit="TFLOP/s", frac=ach / F64_VECTOR_PEAK_TFLOPS,
-                        model=f"{steps_per_matrix:.0f} rotation steps per matrix x 26 useful flop"))
+                        model=f"{steps_per_matrix:.1f} rotation steps per matrix x 26 useful flop (a wave issues 1.33x that: "
+                              f"in every sweep it runs for its longest block)"))
     if per.get("score", 0) > 0:
         by = Q * (3 * 16 * 8 + 4 + 16 + 33)
         ach = by / (per["score"] / 1e3) / 1e9
@@ -296,6 +299,7 @@ def main():
         last = [None]
 
         def step():
+            last[0] = None                  # hand the previous rows back to the pinned pool before new ones are taken
             res.start(sub)
             last[0] = res.finish()
 

@@ -201,7 +201,8 @@ __device__ __forceinline__ double hypot_nr(double a, double b) { return sqrt_nr(
 constexpr int RSQ_NR = 1;      // Newton steps on v_rsq_f64 inside a rotation (1: 5e-15, 2: 1e-16 relative)
 
 __global__ void __launch_bounds__(WAVE)
-tq_bdsqr_kernel(const double *__restrict__ de, int64_t nmat, double *__restrict__ sv, int maxit)
+tq_bdsqr_kernel(const double *__restrict__ de, int64_t nmat, double *__restrict__ sv, int maxit,
+                unsigned long long *__restrict__ stats)
 {
     __shared__ double lds[32 * WAVE];
     const int lane = threadIdx.x;
@@ -238,6 +239,7 @@ tq_bdsqr_kernel(const double *__restrict__ de, int64_t nmat, double *__restrict_
         // "k--" while its neighbours sweep.
         int k = 15, its = 0, l = 0;
         bool noconv = false;
+        uint32_t my_steps = 0, my_sweeps = 0, wave_iters = 0;          // diagnostics (stats != nullptr)
         for (;;) {
             for (;;) {
                 // split point l = largest l <= k with e[l] negligible (or l == 0), unless a negligible
@@ -284,6 +286,16 @@ tq_bdsqr_kernel(const double *__restrict__ de, int64_t nmat, double *__restrict_
             // current step's arithmetic, each hypot shares one rsq with the reciprocal its rotation
             // needs, and a zero pivot is a select, not a branch (f = h = 0 there, so c = s = 0 * rz)
             double gn = E_(l + 1), yn = W_(l + 1);
+            if (stats) {
+                my_steps += (uint32_t)(nm - l + 1);
+                ++my_sweeps;
+                // what the wave pays for this sweep: the longest block among its lanes
+                const int len = nm - l + 1;
+                int mx = len;
+                for (uint64_t act = __ballot(1); act; act &= act - 1)       // only lanes that sweep now (slow; diagnostics)
+                    mx = max(mx, __shfl(len, (int)__builtin_ctzll(act), WAVE));
+                wave_iters += (uint32_t)mx;
+            }
             for (int jj = l; jj <= nm; ++jj) {
                 g = gn;
                 y = yn;
@@ -316,6 +328,18 @@ tq_bdsqr_kernel(const double *__restrict__ de, int64_t nmat, double *__restrict_
         }
 #undef SET_E
 #undef SET_W
+        if (stats) {
+            // wave_iters is only meaningful on lanes that took part in every sweep of the wave: take the maximum
+            uint32_t wi = wave_iters;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) wi = max(wi, (uint32_t)__shfl_xor((int)wi, o, WAVE));
+            if (live) {
+                atomicAdd(&stats[0], 1ull);
+                atomicAdd(&stats[1], (unsigned long long)my_steps);
+                atomicAdd(&stats[3], (unsigned long long)my_sweeps);
+            }
+            if (lane == 0) atomicAdd(&stats[2], 64ull * wi);
+        }
         if (live) {
 #pragma unroll
             for (int i = 0; i < 16; ++i) {

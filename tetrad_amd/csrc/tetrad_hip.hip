@@ -115,6 +115,8 @@ struct tq_ctx {
     hipEvent_t evFork = nullptr, evJoin = nullptr;
     int svd_method = 1;             // 0 = one-sided Jacobi (tq_svd_kernel), 1 = Householder + bidiagonal QR
     int bdsqr_maxit = 60;           // QR sweeps per singular value before a matrix is declared not converged
+    uint64_t *d_bdsqr_stats = nullptr;   // diagnostics (option "bdsqr_stats"): {matrices, rotation steps of all lanes,
+                                         // lane-slots issued (64 x wave iterations), sweeps} summed over the launches
     int scan_wg = 4;                // waves per workgroup of the cooperative scan kernel (1 = one wave per quartet)
     int xcd_remap = 1;              // 1: scan workgroups of one XCD take a contiguous part of the sorted order
     int share_c = 0;                // 1: scan kernel variant that also shares row c inside a workgroup (scan.hpp: SHC;
@@ -487,6 +489,8 @@ int launch_scan_n(tq_ctx *ctx, const uint32_t *dq, const uint32_t *order, int64_
                      : launch_scan_wg<false, 0, 4, true>(ctx, dq, order, Q, stream);
         }
         TQ_WG_CASE(4)
+        TQ_WG_CASE(3)
+        TQ_WG_CASE(6)
         TQ_WG_CASE(16)
         TQ_WG_CASE(8)
 #undef TQ_WG_CASE
@@ -548,7 +552,7 @@ int launch_hqr(tq_ctx *ctx, const uint32_t *cm, const uint32_t *dq, int64_t n, c
     rc = grid_for(ctx, tq_bdsqr_kernel, (nmat + WAVE - 1) / WAVE, &grid, svd_wpc);
     if (rc) return rc;
     hipLaunchKernelGGL(tq_bdsqr_kernel, dim3((unsigned)grid), dim3(WAVE), 0, stream, (const double *)de, nmat, sv,
-                       ctx->bdsqr_maxit);
+                       ctx->bdsqr_maxit, (unsigned long long *)ctx->d_bdsqr_stats);
     TQ_HIP(ctx, hipGetLastError());
     if ((rc = mark(ctx, TAG_BDSQR, stream, lane))) return rc;
     hipLaunchKernelGGL(tq_score_kernel<DEBUG>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream,
@@ -863,6 +867,7 @@ void tq_destroy(tq_ctx *ctx)
     if (ctx->d_de) (void)hipFree(ctx->d_de);
     if (ctx->d_sv) (void)hipFree(ctx->d_sv);
     if (ctx->d_nsnps) (void)hipFree(ctx->d_nsnps);
+    if (ctx->d_bdsqr_stats) (void)hipFree(ctx->d_bdsqr_stats);
     if (ctx->sK) (void)hipStreamDestroy(ctx->sK);
     if (ctx->sC) (void)hipStreamDestroy(ctx->sC);
     if (ctx->sX) {
@@ -1215,14 +1220,23 @@ int tq_set_option(tq_ctx *ctx, const char *name, int64_t value)
         ctx->svd_streams = value ? (int)value : 2;
         return TQ_OK;
     }
+    if (!strcmp(name, "bdsqr_stats")) {                  // 1: allocate + zero the counters, 0: free them
+        if (ctx->d_bdsqr_stats) (void)hipFree(ctx->d_bdsqr_stats);
+        ctx->d_bdsqr_stats = nullptr;
+        if (value) {
+            TQ_HIP(ctx, hipMalloc((void **)&ctx->d_bdsqr_stats, 4 * sizeof(uint64_t)));
+            TQ_HIP(ctx, hipMemset(ctx->d_bdsqr_stats, 0, 4 * sizeof(uint64_t)));
+        }
+        return TQ_OK;
+    }
     if (!strcmp(name, "bdsqr_maxit")) {
         if (value < 0 || value > 1000) return fail(ctx, TQ_ERR_INVALID_ARG, "bdsqr_maxit must be 0..1000");
         ctx->bdsqr_maxit = value ? (int)value : 60;
         return TQ_OK;
     }
     if (!strcmp(name, "scan_wg")) {
-        if (value != 0 && value != 1 && value != 2 && value != 4 && value != 8 && value != 16)
-            return fail(ctx, TQ_ERR_INVALID_ARG, "scan_wg must be 0 (default), 1, 2, 4, 8 or 16");
+        if (value != 0 && value != 1 && value != 2 && value != 3 && value != 4 && value != 6 && value != 8 && value != 16)
+            return fail(ctx, TQ_ERR_INVALID_ARG, "scan_wg must be 0 (default), 1, 2, 3, 4, 6, 8 or 16");
         ctx->scan_wg = value ? (int)value : 4;
         return TQ_OK;
     }
@@ -1456,7 +1470,7 @@ int tq_debug_fetch(tq_ctx *ctx, int which, void *dst, int64_t bytes)
 {
     if (!ctx || !dst || bytes < 0) return TQ_ERR_INVALID_ARG;
     const void *src = which == 0 ? (const void *)ctx->d_cm : which == 1 ? (const void *)ctx->d_de
-                      : which == 2 ? (const void *)ctx->d_sv : nullptr;
+                      : which == 2 ? (const void *)ctx->d_sv : which == 3 ? (const void *)ctx->d_bdsqr_stats : nullptr;
     if (!src) return fail(ctx, TQ_ERR_INVALID_ARG, "tq_debug_fetch: nothing to fetch (which=%d)", which);
     TQ_HIP(ctx, hipSetDevice(ctx->device));
     TQ_HIP(ctx, hipDeviceSynchronize());

@@ -176,7 +176,9 @@ def kernel_rooflines(kms: dict, calls: int, Q: int, S: int, sub: bool, cfg: str)
             for k in out:
                 for name, v in info.get("kernels", {}).items():
                     if name in k["name"]:
-                        k["pmc"] = dict(v, source=info.get("source"), commit=info.get("commit"))
+                        k["pmc"] = dict({x: v[x] for x in ("valu_busy", "lds_busy", "lds_conflict_share") if x in v},
+                                        source="profiles/pmc_busy_latest.json: " + str(info.get("source")),
+                                        commit=info.get("commit"))
         except Exception:
             pass
     return out

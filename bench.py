@@ -399,6 +399,16 @@ def main():
             extra["gather_verified"] = bool(ok)
             extra["gather_pieces"] = P.npieces
             extra["rows_per_piece_per_rank"] = P.part
+            # the SAME workload on one GPU, for a like-for-like scaling figure (the default N = 1 run is c3, a
+            # lighter shape): quoted from the committed one-GPU line of this config, not measured in this run
+            ref = REPO / "profiles" / "r02_pipeline" / f"bench_{cfg}_n1.json"
+            if ref.exists() and not args.quartets and not args.weak:
+                try:
+                    r1 = json.loads(ref.read_text())
+                    extra["same_workload_on_one_gpu"] = dict(value=r1["value"], commit=r1.get("commit"),
+                                                             source=f"profiles/r02_pipeline/{ref.name} (not measured in this run)")
+                except Exception:
+                    pass
 
     hbm_copy = hbm_copy_rate(torch, dev) if rank == 0 else None
 

@@ -717,6 +717,8 @@ struct HostSink {
     size_t off_rscor = 0, off_flags = 0;           // byte offsets of rscor / flags inside a staging piece
     char *stage[2] = {nullptr, nullptr};
     int64_t stage_rows = 0;
+    int64_t single_q0 = 0, single_n = 0;
+    hipStream_t single_stream = nullptr;
     struct Pending { int64_t q0, n; hipEvent_t done; int buf; };
     Pending pend[2];
     int npend = 0;
@@ -758,6 +760,17 @@ struct HostSink {
     // the kernels of chunk [q0, q0+n) have been enqueued on `st`
     int chunk(int64_t q0, int64_t n, hipStream_t st)
     {
+        if (single) {
+            // one piece, one copy, nothing to overlap with: the copy goes behind the kernels on their own stream
+            // and finish() waits for that stream -- no events, no second stream (a 1 000-quartet call is a
+            // dozen HIP calls; every one of them shows)
+            TQ_HIP(ctx, hipMemcpyAsync(stage[0], dev->rstat, off_flags + (size_t)n, hipMemcpyDeviceToHost, st));
+            single_q0 = q0;
+            single_n = n;
+            single_stream = st;
+            ++nchunk;
+            return TQ_OK;
+        }
         hipEvent_t ready, done;
         int rc = pipe_event(ctx, 2 * (nchunk % 4), &ready);
         if (!rc) rc = pipe_event(ctx, 2 * (nchunk % 4) + 1, &done);
@@ -774,17 +787,12 @@ struct HostSink {
                 rc = drain_one();
                 if (rc) return rc;
             }
-            const int b = single ? 0 : (int)(nchunk & 1);
+            const int b = (int)(nchunk & 1);
             char *s = stage[b];
-            if (single) {
-                TQ_HIP(ctx, hipMemcpyAsync(s, dev->rstat, off_flags + (size_t)n, hipMemcpyDeviceToHost, ctx->sC));
-            } else {
-                TQ_HIP(ctx, hipMemcpyAsync(s, dev->rstat + q0 * 2, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->sC));
-                TQ_HIP(ctx, hipMemcpyAsync(s + off_rscor, dev->rscor + q0 * 3, (size_t)n * 24, hipMemcpyDeviceToHost,
-                                           ctx->sC));
-                if (flags)
-                    TQ_HIP(ctx, hipMemcpyAsync(s + off_flags, dev->flags + q0, (size_t)n, hipMemcpyDeviceToHost, ctx->sC));
-            }
+            TQ_HIP(ctx, hipMemcpyAsync(s, dev->rstat + q0 * 2, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->sC));
+            TQ_HIP(ctx, hipMemcpyAsync(s + off_rscor, dev->rscor + q0 * 3, (size_t)n * 24, hipMemcpyDeviceToHost, ctx->sC));
+            if (flags)
+                TQ_HIP(ctx, hipMemcpyAsync(s + off_flags, dev->flags + q0, (size_t)n, hipMemcpyDeviceToHost, ctx->sC));
             TQ_HIP(ctx, hipEventRecord(done, ctx->sC));
             pend[npend++] = Pending{q0, n, done, b};
             if (npend == 2) {                       // copy out the older piece while the GPU works on
@@ -798,6 +806,14 @@ struct HostSink {
     int finish()
     {
         int rc = TQ_OK;
+        if (single && nchunk) {
+            TQ_HIP(ctx, hipStreamSynchronize(single_stream));
+            const char *s = stage[0];
+            memcpy(rstat + single_q0 * 2, s, (size_t)single_n * 8);
+            memcpy(rscor + single_q0 * 3, s + off_rscor, (size_t)single_n * 24);
+            if (flags) memcpy(flags + single_q0, s + off_flags, (size_t)single_n);
+            return TQ_OK;
+        }
         while (npend && !rc) rc = drain_one();
         if (!rc && hipStreamSynchronize(ctx->sC) != hipSuccess) rc = fail(ctx, TQ_ERR_HIP, "result copy failed");
         return rc;

@@ -177,6 +177,16 @@ def test_error_behaviour(oracle):
         assert flags[0] & 1 and rstat[0, 1] == 0 and np.all(rscor == 0.001)
         rstat, rscor, flags = eng.resolve(np.zeros((0, 4), np.uint32), False)
         assert rstat.shape == (0, 2)
+        # a large batch is validated on the host while the GPU already works on it: same error, and the
+        # context stays usable
+        big = np.tile(np.array([[0, 1, 2, 3]], np.uint32), (70_000, 1))
+        big[-1, 2] = 5
+        with pytest.raises(TetradHipError) as e:
+            eng.resolve(big, False)
+        assert e.value.code == -1 and "69999" in str(e.value)
+        big[-1, 2] = 2
+        rstat, rscor, flags = eng.resolve(big, False)
+        assert (flags & 1).all() and (rstat[:, 1] == 0).all()
 
 
 def test_device_pointer_api_and_unranking(engine):

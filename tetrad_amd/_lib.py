@@ -54,7 +54,21 @@ def build(force: bool = False, verbose: bool = False) -> Path:
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
+    _stamp_commit()
     return LIB_PATH
+
+
+def _stamp_commit() -> None:
+    """Remember which commit the library was built from (bench.py quotes it; the GPU box has no .git)."""
+    repo = CSRC.parents[1]
+    try:
+        head = subprocess.check_output(["git", "-C", str(repo), "rev-parse", "--short", "HEAD"],
+                                       stderr=subprocess.DEVNULL).decode().strip()
+        dirty = subprocess.check_output(["git", "-C", str(repo), "status", "--porcelain", "--untracked-files=no"],
+                                        stderr=subprocess.DEVNULL).decode().strip()
+        (repo / ".build_commit").write_text(head + ("+uncommitted" if dirty else "") + "\n")
+    except Exception:
+        pass
 
 
 _lib = None

@@ -67,7 +67,7 @@ __global__ void tq_boot_perm_kernel(const int64_t *__restrict__ spans, const int
 __global__ void tq_boot_build_kernel(const uint8_t *__restrict__ seqarr, int64_t S0,
                                      const uint32_t *__restrict__ src_col, const uint32_t *__restrict__ site_locus,
                                      int64_t S, int64_t Sp, int64_t W, int32_t T, uint64_t seed,
-                                     uint8_t *__restrict__ rows, uint8_t *__restrict__ nib, uint8_t *__restrict__ nib4,
+                                     uint8_t *__restrict__ rows, uint8_t *__restrict__ nib,
                                      uint4 *__restrict__ planes, uint32_t *__restrict__ planes3,
                                      uint32_t *__restrict__ runbeg)
 {
@@ -112,7 +112,6 @@ __global__ void tq_boot_build_kernel(const uint8_t *__restrict__ seqarr, int64_t
     planes[t * W + w] = make_uint4(mm, b0, b1, rb);
     store_planes3(planes3, runbeg, t, W, w, mm, b0, b1, rb);
     reinterpret_cast<uint4 *>(nib + t * (Sp / 2))[w] = make_uint4(nw[0], nw[1], nw[2], nw[3]);
-    reinterpret_cast<uint4 *>(nib4 + t * (Sp / 2))[w] = make_uint4(nw[0] << 2, nw[1] << 2, nw[2] << 2, nw[3] << 2);
 }
 
 // replicate currently on the device -> the reference's tmparr (0..3, 78) / tmpmap layout

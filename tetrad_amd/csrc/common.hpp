@@ -16,7 +16,6 @@ constexpr double DEGENERATE_REL_GAP = 1e-9;
 struct DevData {
     const uint8_t *rows;
     const uint8_t *nib;     // [T][Sp/2] two base codes per byte (see nib_offset)
-    const uint8_t *nib4;    // same layout, every code pre-multiplied by 4 (row c of a quartet, row a of a pair)
     const uint4 *planes;    // [T][W] {miss, p0, p1, runbeg}
     const uint32_t *planes3; // [T][W][3] {miss, p0, p1}: the compact copy the cooperative scan streams
     const uint32_t *runbeg;  // [W] run-begin bits (the same for every taxon)

@@ -17,7 +17,7 @@ __device__ __forceinline__ void store_planes3(uint32_t *planes3, uint32_t *runbe
 // ------------------------------------------------------------------------------------
 __global__ void tq_prepare_rows(const uint8_t *__restrict__ raw, const uint32_t *__restrict__ locus,
                                 int64_t S, int64_t Sp, int64_t W, int32_t T, uint8_t *__restrict__ rows,
-                                uint8_t *__restrict__ nib, uint8_t *__restrict__ nib4, uint4 *__restrict__ planes,
+                                uint8_t *__restrict__ nib, uint4 *__restrict__ planes,
                                 uint32_t *__restrict__ planes3, uint32_t *__restrict__ runbeg)
 {
     int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -45,7 +45,6 @@ __global__ void tq_prepare_rows(const uint8_t *__restrict__ raw, const uint32_t 
     planes[t * W + w] = make_uint4(mm, b0, b1, rb);
     store_planes3(planes3, runbeg, t, W, w, mm, b0, b1, rb);
     reinterpret_cast<uint4 *>(nib + t * (Sp / 2))[w] = make_uint4(nw[0], nw[1], nw[2], nw[3]);
-    reinterpret_cast<uint4 *>(nib4 + t * (Sp / 2))[w] = make_uint4(nw[0] << 2, nw[1] << 2, nw[2] << 2, nw[3] << 2);
 }
 
 // ------------------------------------------------------------------------------------

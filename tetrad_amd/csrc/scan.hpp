@@ -261,11 +261,11 @@ tq_scan_kernel(DevData d, const uint32_t *__restrict__ quartets, const uint32_t 
 // one block of NW quartets per workgroup (grid = number of blocks, dispatched in sorted order).
 // Quartets that share their first two taxa share two of their four rows, so what depends only on
 // (a,b) is fetched and pre-combined ONCE per workgroup per 2048-site step by three 64-lane jobs dealt
-// round-robin to the waves: jobs 0-1 turn the nibble codes of a (x4 copy) and b into the pattern
+// round-robin to the waves: jobs 0-1 turn the nibble codes of a and b into the pattern
 // partial ((a<<2)+b)<<4 of 16 sites per lane, job 2 turns the 12-byte plane records of a and b and
 // the run-begin word into {p0a, p1a, Ma|Mb, (p0a^p0b)|(p1a^p1b)} + B.  The image (3.25 KiB) is
-// double-buffered in LDS with one barrier per step.  Every wave streams its own rows c (x4 nibble
-// copy) and d (nibble copy) and their 12-byte plane records straight to registers (one register set:
+// double-buffered in LDS with one barrier per step.  Every wave streams its own rows c and d
+// (nibble copy) and their 12-byte plane records straight to registers (one register set:
 // the loads of step t+1 are issued inside step t once the pattern bytes are parked, 72 VGPRs = 7 waves/SIMD):
 // 3.5 KiB per wave-step + 3.75/NW KiB shared (12 KiB for independent waves on byte rows).  A wave
 // whose (a,b) differs from the leader's (group boundary in the sorted order) builds its own partial
@@ -273,7 +273,7 @@ tq_scan_kernel(DevData d, const uint32_t *__restrict__ quartets, const uint32_t 
 // VALU 77 %, LDS 78 % and the L2 -> CU path ~90 % busy at the same time.
 // ------------------------------------------------------------------------------------
 struct OwnRegs {
-    uint4 c, d, pc, pd;      // nibble codes of rows c (x4) and d (32 sites each), their plane records (.w = 0)
+    uint4 c, d, pc, pd;      // nibble codes of rows c and d (32 sites each), their plane records (.w = 0)
 };
 
 // 16-byte load at a wave-uniform base + 32-bit per-lane byte offset (lets the compiler use the
@@ -304,11 +304,11 @@ struct OwnOff {
     uint32_t c, d, pc, pd;
 };
 
-__device__ __forceinline__ void load_own(OwnRegs &r, const uint8_t *nib, const uint8_t *nib4, const uint8_t *planes3,
+__device__ __forceinline__ void load_own(OwnRegs &r, const uint8_t *nib, const uint8_t *planes3,
                                          const OwnOff &o, int tile)
 {
     const uint32_t tn = (uint32_t)tile * (TILE / 2), tp = (uint32_t)tile * (WAVE * 12);
-    r.c = ld16(nib4, o.c + tn);                  // codes of row c arrive pre-multiplied by 4
+    r.c = ld16(nib, o.c + tn);                   // plain codes; the factor 4 is the shift of a v_lshl_add_u32
     r.d = ld16(nib, o.d + tn);
     r.pc = ld12(planes3, o.pc + tp);
     r.pd = ld12(planes3, o.pd + tp);
@@ -326,7 +326,7 @@ __device__ __forceinline__ void cd_pair(uint32_t cw, uint32_t dw, uint32_t &lo, 
 constexpr int SHARED_SLOTS = 208;
 // SHC ("share row c"): when every quartet of a block has the leader's (a,b,c) -- the normal case for
 // lexicographic enumerations, combinations.py:40-55, and frequent in an (a,b,c)-sorted random sample -- one more
-// job fetches the nibble codes (x4 copy) and the plane record of row c once per workgroup and step into two more
+// job fetches the nibble codes and the plane record of row c once per workgroup and step into two more
 // panels of the image (slots 208-271, 272-335); the waves then read their row c from LDS and stream only row d
 // from the L2: 2.6 KiB instead of 4.4 KiB per quartet-step through the L2 -> CU path.
 // MEASURED SLOWER (profiles/r02_*/share_c_ab.txt): c2 lexicographic, where every block qualifies, 1.75 -> 2.13 ms;
@@ -356,16 +356,15 @@ tq_scan_wg_kernel(DevData d, const uint32_t *__restrict__ quartets, const uint32
     const int64_t nblk = (Q + NW - 1) / NW;
     const uint8_t *rows = d.rows;
     const uint8_t *nib = d.nib;
-    const uint8_t *nib4 = d.nib4;
     const uint8_t *planes = reinterpret_cast<const uint8_t *>(d.planes);
     const uint8_t *planes3 = reinterpret_cast<const uint8_t *>(d.planes3);
     const uint8_t *runbeg = reinterpret_cast<const uint8_t *>(d.runbeg);
     const uint32_t pitch = (uint32_t)d.pitch, npitch = pitch / 2, wpitch = (uint32_t)d.W * 16u,
                    w3pitch = (uint32_t)d.W * 12u;
-    // cooperative jobs per step: 0,1 = nibble codes of rows a (x4 copy) and b for sites 0-15 / 16-31
+    // cooperative jobs per step: 0,1 = nibble codes of rows a and b for sites 0-15 / 16-31
     // of every lane -> abp panels 0,1; 2 = plane records of a and b (+ run-begin bits) -> r1, B.
     // Wave w takes the jobs j with j % NW == w.
-    // With SHC: 3 = nibble codes (x4 copy) and plane record of the block's common row c.
+    // With SHC: 3 = nibble codes and plane record of the block's common row c.
     constexpr int NJOB = SHC ? 4 : 3, JPW = (NJOB + NW - 1) / NW;        // jobs per wave
     __syncthreads();
 
@@ -428,9 +427,9 @@ tq_scan_wg_kernel(DevData d, const uint32_t *__restrict__ quartets, const uint32
         auto job_of = [=](int i) { return w + i * NW; };                       // wave-uniform
         auto ld8 = [=](const uint8_t *base, uint32_t off) -> uint2 { return *reinterpret_cast<const uint2 *>(base + off); };
         auto fetch_x = [=](int job, int tile) -> uint4 {
-            if (job < 2) {                                   // 8 nibble bytes (16 sites) of a (x4) and of b
+            if (job < 2) {                                   // 8 nibble bytes (16 sites) of a and of b
                 const uint32_t o = (uint32_t)lane * 16u + (uint32_t)job * 8u + (uint32_t)tile * (TILE / 2);
-                const uint2 xa = ld8(nib4, la * npitch + o), xb = ld8(nib, lb * npitch + o);
+                const uint2 xa = ld8(nib, la * npitch + o), xb = ld8(nib, lb * npitch + o);
                 return make_uint4(xa.x, xa.y, xb.x, xb.y);
             }
             if (job == 2) {
@@ -438,7 +437,7 @@ tq_scan_wg_kernel(DevData d, const uint32_t *__restrict__ quartets, const uint32
                 r.w = *reinterpret_cast<const uint32_t *>(runbeg + (uint32_t)lane * 4u + (uint32_t)tile * (WAVE * 4));
                 return r;
             }
-            if (SHC && job == 3 && shc) return ld16(nib4, lc * npitch + (uint32_t)lane * 16u + (uint32_t)tile * (TILE / 2));
+            if (SHC && job == 3 && shc) return ld16(nib, lc * npitch + (uint32_t)lane * 16u + (uint32_t)tile * (TILE / 2));
             return make_uint4(0, 0, 0, 0);
         };
         auto fetch_y = [=](int job, int tile) -> uint4 {
@@ -451,13 +450,14 @@ tq_scan_wg_kernel(DevData d, const uint32_t *__restrict__ quartets, const uint32
         // run-begin words 192-207 (64 dwords)
         auto publish = [=](uint4 *buf, int job, uint4 x, uint4 y) {
             if (job < 2) {
-                const uint32_t h = 0xF0F0F0F0u, s0 = x.x + x.z, s1 = x.y + x.w;   // a*4+b per nibble
+                // a*4+b per nibble: codes are 0..3, so the packed word can be shifted as a whole
+                const uint32_t h = 0xF0F0F0F0u, s0 = (x.x << 2) + x.z, s1 = (x.y << 2) + x.w;
                 buf[job * 64 + lane] = make_uint4((s0 << 4) & h, s0 & h, (s1 << 4) & h, s1 & h);
             } else if (job == 2) {
                 buf[128 + lane] = make_uint4(x.y, x.z, x.x | y.x, (x.y ^ y.y) | (x.z ^ y.z));
                 reinterpret_cast<uint32_t *>(buf + 192)[lane] = x.w;
             } else if (SHC && job == 3 && shc) {
-                buf[SHARED_SLOTS + lane] = x;                  // nibble codes of row c, pre-multiplied by 4
+                buf[SHARED_SLOTS + lane] = x;                  // nibble codes of row c
                 buf[SHARED_SLOTS + 64 + lane] = y;             // its plane record {miss, p0, p1, 0}
             }
         };
@@ -468,7 +468,7 @@ tq_scan_wg_kernel(DevData d, const uint32_t *__restrict__ quartets, const uint32
                 r.d = ld16(nib, oo.d + tn);
                 r.pd = ld12(planes3, oo.pd + tp);
             } else {
-                load_own(r, nib, nib4, planes3, oo, tile);
+                load_own(r, nib, planes3, oo, tile);
             }
         };
 
@@ -515,13 +515,15 @@ tq_scan_wg_kernel(DevData d, const uint32_t *__restrict__ quartets, const uint32
                 Bw = pa.w;
             }
             const uint32_t C = count_mask_shared<SUB>(r1, Bw, own.pc, own.pd, lane, tile_carry);
-            // own.c holds 4*c, own.d holds d, one site per nibble: their sum is the (c<<2|d) nibble;
+            // own.c and own.d hold the codes of rows c and d, one site per nibble (codes are 0..3, so the packed
+            // word can be shifted as a whole): (c << 2) + d is the (c<<2|d) nibble, one v_lshl_add_u32 per dword;
             // the (a<<6|b<<4) byte of the same site sits in the high nibbles of abp
             // (the mask lives in an SGPR so that (s & m) | ab is one v_and_or_b32; as a literal it
             // cannot be encoded in a three-operand instruction and costs a second one)
             uint32_t m;
             asm("s_mov_b32 %0, 0x0f0f0f0f" : "=s"(m));
-            const uint32_t s0 = own.c.x + own.d.x, s1 = own.c.y + own.d.y, s2 = own.c.z + own.d.z, s3 = own.c.w + own.d.w;
+            const uint32_t s0 = (own.c.x << 2) + own.d.x, s1 = (own.c.y << 2) + own.d.y, s2 = (own.c.z << 2) + own.d.z,
+                           s3 = (own.c.w << 2) + own.d.w;
             uint32_t pat[8];
             pat[0] = and_or(s0, m, ab0.x); pat[1] = and_or(s0 >> 4, m, ab0.y);
             pat[2] = and_or(s1, m, ab0.z); pat[3] = and_or(s1 >> 4, m, ab0.w);

@@ -12,7 +12,7 @@
 // Data layout in HBM (built once per replicate by tq_set_data / tq_bootstrap):
 //   rows    u8   [T][Sp]   base code 0..3 per site, missing/pad -> 0  (Sp = S rounded up to 2048;
 //                          inside each 2048-site step the bytes sit in two 1 KiB panels, row_offset())
-//   nib     u8   [T][Sp/2] the same codes, two per byte (nib_offset()); nib4: codes pre-multiplied by 4
+//   nib     u8   [T][Sp/2] the same codes, two per byte (nib_offset())
 //   planes  u32x4[T][W]    per 32 sites: {missing bits, base bit 0, base bit 1, run-begin bits}, W = Sp/32
 //   planes3 u32x3[T][W]    compact copy {missing, bit 0, bit 1}; runbeg u32 [W] run-begin bits, stored once
 //
@@ -401,7 +401,6 @@ DevData dev_data(const tq_ctx *ctx)
     DevData d;
     d.rows = ctx->d_rows;
     d.nib = ctx->d_nib;
-    d.nib4 = ctx->d_nib + (size_t)ctx->T * (size_t)ctx->data_capacity / 2;
     d.planes = ctx->d_planes;
     d.planes3 = ctx->d_planes3;
     d.runbeg = ctx->d_planes3 + (size_t)ctx->T * (size_t)ctx->plane_cap_W * 3;
@@ -828,9 +827,16 @@ struct HostSink {
     }
 };
 
-// device quartets -> host results (synchronous)
+struct NoHostWork {
+    int operator()() const { return TQ_OK; }
+};
+
+// device quartets -> host results (synchronous).  `while_gpu_works()` runs on the host after everything has been
+// enqueued and before the results are waited for (a non-zero return aborts the call after the streams have drained).
+template <typename F = NoHostWork>
 int resolve_to_host(tq_ctx *ctx, const uint32_t *dq, int64_t Q, int subsample, bool input_sorted, uint32_t *rstat,
-                    double *rscor, uint8_t *flags, uint32_t *d_rstat, double *d_rscor, uint8_t *d_flags)
+                    double *rscor, uint8_t *flags, uint32_t *d_rstat, double *d_rscor, uint8_t *d_flags,
+                    F &&while_gpu_works = F())
 {
     OutPtrs out{d_rstat, d_rscor, d_flags, nullptr, nullptr, nullptr};
     HostSink sink{ctx, rstat, rscor, flags, &out};
@@ -839,6 +845,7 @@ int resolve_to_host(tq_ctx *ctx, const uint32_t *dq, int64_t Q, int subsample, b
     rc = launch(ctx, dq, Q, subsample, false, input_sorted, out, ctx->sK,
                 [&](int64_t q0, int64_t n, hipStream_t st) { return sink.chunk(q0, n, st); });
     if (rc) return rc;
+    if ((rc = while_gpu_works())) return rc;          // ~HostSink drains the streams
     return sink.finish();
 }
 
@@ -951,7 +958,7 @@ int tq_set_data(tq_ctx *ctx, const uint8_t *tmparr, int64_t T, int64_t S, const 
     uint8_t *d_raw = nullptr;
     uint32_t *d_loc = nullptr;
     TQ_HIP(ctx, hipMalloc((void **)&ctx->d_rows, (size_t)(T * Sp)));
-    TQ_HIP(ctx, hipMalloc((void **)&ctx->d_nib, (size_t)(T * Sp)));             // nib, then nib4
+    TQ_HIP(ctx, hipMalloc((void **)&ctx->d_nib, (size_t)(T * Sp / 2)));
     TQ_HIP(ctx, hipMalloc((void **)&ctx->d_planes, (size_t)(T * W) * sizeof(uint4)));
     TQ_HIP(ctx, hipMalloc((void **)&ctx->d_planes3, (size_t)(T * W * 3 + W) * sizeof(uint32_t)));
     ctx->plane_cap_W = W;
@@ -966,7 +973,7 @@ int tq_set_data(tq_ctx *ctx, const uint8_t *tmparr, int64_t T, int64_t S, const 
     if (e == hipSuccess) {
         const int64_t n = T * W;
         hipLaunchKernelGGL(tq_prepare_rows, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, d_raw, d_loc, S, Sp,
-                           W, (int32_t)T, ctx->d_rows, ctx->d_nib, ctx->d_nib + (size_t)(T * Sp / 2), ctx->d_planes,
+                           W, (int32_t)T, ctx->d_rows, ctx->d_nib, ctx->d_planes,
                            ctx->d_planes3,
                            ctx->d_planes3 + (size_t)T * (size_t)W * 3);
         e = hipGetLastError();
@@ -1091,23 +1098,37 @@ int tq_resolve_debug(tq_ctx *ctx, const uint32_t *quartets, int64_t Q, int subsa
     if (rc) return rc;
     if (Q == 0) return TQ_OK;
     TQ_HIP(ctx, hipSetDevice(ctx->device));
-    // taxon indices are checked on the host here; the kernel re-checks and flags them
-    // ... and the same pass notices input that already is in (a,b,c) order -- the lexicographic
-    // chunks of the reference's default mode (combinations.py:40-55) are -- so that the device sort
-    // (about twenty small kernels, most of the time of a chunk of a few thousand quartets) is skipped
-    bool sorted = true;
-    uint64_t prev_key = 0;
-    for (int64_t i = 0; i < Q; ++i) {
-        const uint32_t *q = quartets + i * 4;
-        for (int k = 0; k < 4; ++k)
-            if (q[k] >= (uint64_t)ctx->T)
-                return fail(ctx, TQ_ERR_INVALID_ARG, "quartet %lld has taxon index %u >= T=%lld", (long long)i, q[k],
-                            (long long)ctx->T);
-        const uint64_t key = ((uint64_t)q[0] << 42) | ((uint64_t)q[1] << 21) | (uint64_t)q[2];
-        sorted &= key >= prev_key;
-        prev_key = key;
+    // Taxon indices are checked on the host (the kernels re-check and flag them, and never dereference a bad
+    // one).  For chunks of the size the reference's distributor hands out the same pass notices input that
+    // already is in (a,b,c) order -- its default mode's lexicographic chunks are (combinations.py:40-55) -- so
+    // that the device sort (about twenty small kernels, most of the time of a chunk of a few thousand
+    // quartets) is skipped.  A large batch is checked WHILE THE GPU WORKS on it (the pass over 16 B per quartet
+    // costs ~1 ms per 1e6 on the host, the sort it could save 0.2 ms).
+    constexpr int64_t CHECK_FIRST = 1 << 16;
+    auto check_indices = [ctx, quartets, Q]() -> int {
+        const uint32_t T = (uint32_t)ctx->T;
+        uint32_t worst = 0;
+        for (int64_t i = 0; i < 4 * Q; ++i) worst = quartets[i] > worst ? quartets[i] : worst;      // vectorises
+        if (worst < T) return TQ_OK;
+        for (int64_t i = 0; i < 4 * Q; ++i)
+            if (quartets[i] >= T)
+                return fail(ctx, TQ_ERR_INVALID_ARG, "quartet %lld has taxon index %u >= T=%lld", (long long)(i / 4),
+                            quartets[i], (long long)ctx->T);
+        return TQ_OK;
+    };
+    bool input_sorted = false;
+    if (Q <= CHECK_FIRST) {
+        if ((rc = check_indices())) return rc;
+        bool sorted = true;
+        uint64_t prev_key = 0;
+        for (int64_t i = 0; i < Q; ++i) {
+            const uint32_t *q = quartets + i * 4;
+            const uint64_t key = ((uint64_t)q[0] << 42) | ((uint64_t)q[1] << 21) | (uint64_t)q[2];
+            sorted &= key >= prev_key;
+            prev_key = key;
+        }
+        input_sorted = sorted && ctx->T < (1 << 21);
     }
-    const bool input_sorted = sorted && ctx->T < (1 << 21);
     const bool debug = cmats || svds || ranks;
     const size_t o_q = 0;
     const size_t o_rstat = align_up(o_q + (size_t)Q * 16, 256);
@@ -1122,9 +1143,18 @@ int tq_resolve_debug(tq_ctx *ctx, const uint32_t *quartets, int64_t Q, int subsa
     char *base = (char *)ctx->d_scratch;
     // quartets H2D on the compute stream (asynchronous when the caller's array is page-locked)
     TQ_HIP(ctx, hipMemcpyAsync(base + o_q, quartets, (size_t)Q * 16, hipMemcpyHostToDevice, ctx->sK));
-    if (!debug)
-        return resolve_to_host(ctx, (const uint32_t *)(base + o_q), Q, subsample, input_sorted, rstat, rscor, flags,
-                               (uint32_t *)(base + o_rstat), (double *)(base + o_rscor), (uint8_t *)(base + o_flags));
+    if (!debug) {
+        if (Q <= CHECK_FIRST)
+            return resolve_to_host(ctx, (const uint32_t *)(base + o_q), Q, subsample, input_sorted, rstat, rscor, flags,
+                                   (uint32_t *)(base + o_rstat), (double *)(base + o_rscor), (uint8_t *)(base + o_flags));
+        return resolve_to_host(ctx, (const uint32_t *)(base + o_q), Q, subsample, false, rstat, rscor, flags,
+                               (uint32_t *)(base + o_rstat), (double *)(base + o_rscor), (uint8_t *)(base + o_flags),
+                               check_indices);
+    }
+    if (Q > CHECK_FIRST && (rc = check_indices())) {
+        (void)hipStreamSynchronize(ctx->sK);
+        return rc;
+    }
     OutPtrs out;
     out.rstat = (uint32_t *)(base + o_rstat);
     out.rscor = (double *)(base + o_rscor);
@@ -1370,7 +1400,7 @@ int tq_bootstrap_async(tq_ctx *ctx, const int64_t *lidxs, int64_t n, uint64_t se
         free_data(ctx);
         const int64_t capSp = (int64_t)align_up((size_t)(Sp + Sp / 8), TILE);   // head-room: replicate lengths vary
         TQ_HIP(ctx, hipMalloc((void **)&ctx->d_rows, (size_t)(T * capSp)));
-        TQ_HIP(ctx, hipMalloc((void **)&ctx->d_nib, (size_t)(T * capSp)));      // nib, then nib4
+        TQ_HIP(ctx, hipMalloc((void **)&ctx->d_nib, (size_t)(T * capSp / 2)));
         TQ_HIP(ctx, hipMalloc((void **)&ctx->d_planes, (size_t)(T * (capSp / 32)) * sizeof(uint4)));
         TQ_HIP(ctx, hipMalloc((void **)&ctx->d_planes3, (size_t)(T * (capSp / 32) * 3 + capSp / 32) * sizeof(uint32_t)));
         ctx->plane_cap_W = capSp / 32;
@@ -1395,7 +1425,6 @@ int tq_bootstrap_async(tq_ctx *ctx, const int64_t *lidxs, int64_t n, uint64_t se
     const int64_t nw = T * W;
     hipLaunchKernelGGL(tq_boot_build_kernel, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, stream, ctx->d_seqarr,
                        ctx->src_S0, src_col, site_locus, S, Sp, W, (int32_t)T, seed_ambig, ctx->d_rows, ctx->d_nib,
-                       ctx->d_nib + (size_t)T * (size_t)ctx->data_capacity / 2,
                        ctx->d_planes, ctx->d_planes3, ctx->d_planes3 + (size_t)T * (size_t)ctx->plane_cap_W * 3);
     TQ_HIP(ctx, hipGetLastError());
     ctx->T = T;

@@ -27,9 +27,13 @@ def main():
     ap.add_argument("--api", default="dev", choices=["dev", "host"])
     ap.add_argument("--sort", default="none", choices=["none", "lex"], help="order of the quartet list")
     ap.add_argument("--opt", action="append", default=[], help="name=v1,v2,...  (engine option axis)")
+    ap.add_argument("--lib", default="", help="load this build of the library instead of the in-tree one (A/B of two builds)")
     args = ap.parse_args()
     import torch
     from tetrad_amd import synth
+    if args.lib:
+        from tetrad_amd import _lib
+        _lib.LIB_PATH = Path(args.lib).resolve()
     from tetrad_amd.engine import QuartetEngine, pinned_empty
 
     T, S, _ = synth.CONFIGS[args.config]

@@ -231,6 +231,12 @@ int tq_format_qmc(const uint32_t *quartets, const uint32_t *rstat, const double 
                   int weights, int64_t min_snps, double min_ratio, char *out, int64_t cap,
                   int64_t *written, int64_t *n_lines);
 
+/* Lexicographic unranking on the host (no device involved): quartets[i] = the 4-combination of range(T) with
+ * rank ranks[i] (or first_rank + i when ranks is NULL), i.e. _index_to_combination (combinations.py:94-106) for
+ * every sampled index / islice(combinations(range(T), 4), first_rank, first_rank + Q) (combinations.py:40-55).
+ * TQ_ERR_INVALID_ARG when a rank is >= C(T,4).                                                     */
+int tq_unrank(const uint64_t *ranks, uint64_t first_rank, int64_t Q, int64_t T, uint32_t *quartets);
+
 /* Quartet supertree (host code, no device involved): weighted Quartet MaxCut over `n` resolved quartets
  * splits u32[n,4] = "a,b|c,d" (the taxa of a wQMC input line, run_inference.py:264-305), weights f64[n] or
  * NULL (all 1), taxa 0..ntaxa-1.  Writes the unrooted tree as newick with the taxon numbers as tip labels

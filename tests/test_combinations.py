@@ -1,0 +1,67 @@
+"""Host-side mirror of the reference's quartet producers (tetrad/src/combinations.py) and the native unranker
+`tq_unrank` (host code of the C ABI: runs without a GPU)."""
+from itertools import combinations, islice
+from math import comb
+
+import numpy as np
+import pytest
+
+from tetrad_amd import combinations as C
+from tetrad_amd import synth
+
+
+def _index_to_combination(index, n):
+    """what combinations.py:94-106 computes, spelled out for the test (k = 4)"""
+    out = []
+    for i in range(n):
+        if len(out) == 4:
+            break
+        block = comb(n - i - 1, 4 - len(out) - 1)
+        if block > index:
+            out.append(i)
+        else:
+            index -= block
+    return tuple(out)
+
+
+@pytest.mark.parametrize("n", [4, 5, 9, 16])
+def test_unrank_is_itertools_order(n):
+    want = np.array(list(combinations(range(n), 4)), np.uint32)
+    np.testing.assert_array_equal(C.unrank(np.arange(comb(n, 4)), n), want)
+    np.testing.assert_array_equal(C.unrank(None, n, 0, comb(n, 4)), want)
+    np.testing.assert_array_equal(np.concatenate(list(C.iter_chunks_full(n, 7))), want)
+    assert C.get_chunks_info(n, 7)[-1][1] == comb(n, 4)
+
+
+def test_unrank_random_ranks_large_t():
+    rng = np.random.default_rng(0)
+    for n in (64, 256, 1700):
+        r = rng.choice(comb(n, 4), size=300, replace=False)
+        got = C.unrank(r, n)
+        np.testing.assert_array_equal(got, np.array([_index_to_combination(int(i), n) for i in r], np.uint32))
+        np.testing.assert_array_equal(got, synth.unrank_quartets(r, n))
+        # first and last combination
+    np.testing.assert_array_equal(C.unrank([0, comb(256, 4) - 1], 256), [[0, 1, 2, 3], [252, 253, 254, 255]])
+    start = comb(100, 4) - 5
+    np.testing.assert_array_equal(C.get_combinations_from_chunk(100, start, start + 50),
+                                  np.array(list(islice(combinations(range(100), 4), start, None)), np.uint32))
+
+
+def test_random_sample_makes_the_reference_draw():
+    """One rng.choice on the caller's Generator (combinations.py:113): same sample, same Generator state after."""
+    a, b = np.random.default_rng(5), np.random.default_rng(5)
+    q = C.random_combination_sample_via_index(40, 500, a)
+    idx = b.choice(comb(40, 4), size=500, replace=False)
+    np.testing.assert_array_equal(q, np.array([_index_to_combination(int(i), 40) for i in idx], np.uint32))
+    assert a.bit_generator.state == b.bit_generator.state
+    chunks = list(C.iter_chunks_random(40, 500, 128, np.random.default_rng(5)))
+    assert [len(c) for c in chunks] == [128, 128, 128, 116]
+    np.testing.assert_array_equal(np.concatenate(chunks), q)
+
+
+def test_unrank_rejects_ranks_beyond_the_space():
+    from tetrad_amd._lib import TetradHipError
+    with pytest.raises(TetradHipError):
+        C.unrank([comb(10, 4)], 10)
+    with pytest.raises(TetradHipError):
+        C.unrank(None, 10, comb(10, 4) - 1, 2)

@@ -130,3 +130,44 @@ inline int64_t format_qmc(const uint32_t *quartets, const uint32_t *rstat, const
     if (n_lines) *n_lines = lines;
     return p - out;
 }
+
+// lexicographic unranking of 4-combinations on the host (combinations.py:94-106, `_index_to_combination`, one
+// O(T) Python loop per quartet in the reference): rank -> (a,b,c,d), a<b<c<d, by walking the same
+// "does the block of combinations that start with t contain the rank?" comparisons with closed-form binomials
+inline uint64_t host_choose(uint64_t n, int k)
+{
+    switch (k) {
+    case 0: return 1;
+    case 1: return n;
+    case 2: return n < 2 ? 0 : n * (n - 1) / 2;
+    default: return n < 3 ? 0 : n * (n - 1) / 2 * (n - 2) / 3;
+    }
+}
+
+inline uint64_t host_choose4(uint64_t n) { return n < 4 ? 0 : n * (n - 1) / 2 * (n - 2) / 3 * (n - 3) / 4; }
+
+inline void unrank_host(const uint64_t *ranks, uint64_t first_rank, int64_t Q, int32_t T, uint32_t *quartets)
+{
+    // With k picks left and candidates p..T-1, the combinations whose next pick is < t number
+    // C(T-p, k) - C(T-t, k); the pick is the largest t for which that is <= the remaining index: a binary
+    // search per level (about 4 x log2 T steps instead of the reference's walk over all T candidates).
+    auto choose = [](uint64_t n, int k) { return k == 4 ? host_choose4(n) : host_choose(n, k); };
+    for (int64_t i = 0; i < Q; ++i) {
+        uint64_t index = ranks ? ranks[i] : first_rank + (uint64_t)i;
+        uint32_t out[4];
+        uint32_t p = 0;
+        for (int k = 4; k >= 1; --k) {
+            const uint64_t all = choose((uint64_t)(T - p), k);
+            uint32_t lo = p, hi = (uint32_t)(T - k);                  // the pick lies in [lo, hi]
+            while (lo < hi) {
+                const uint32_t mid = lo + (hi - lo + 1) / 2;
+                if (all - choose((uint64_t)(T - mid), k) <= index) lo = mid;
+                else hi = mid - 1;
+            }
+            index -= all - choose((uint64_t)(T - lo), k);
+            out[4 - k] = lo;
+            p = lo + 1;
+        }
+        memcpy(quartets + 4 * i, out, 16);
+    }
+}

@@ -1543,6 +1543,20 @@ int tq_format_qmc(const uint32_t *quartets, const uint32_t *rstat, const double 
     return n < 0 ? TQ_ERR_OOM : TQ_OK;
 }
 
+int tq_unrank(const uint64_t *ranks, uint64_t first_rank, int64_t Q, int64_t T, uint32_t *quartets)
+{
+    if (Q < 0 || T < 4 || T > 100000 || (Q > 0 && !quartets)) return TQ_ERR_INVALID_ARG;     // C(T,4) must fit 64 bits
+    const uint64_t t = (uint64_t)T, total = t * (t - 1) / 2 * (t - 2) / 3 * (t - 3) / 4;
+    if (ranks) {
+        for (int64_t i = 0; i < Q; ++i)
+            if (ranks[i] >= total) return TQ_ERR_INVALID_ARG;
+    } else if (first_rank + (uint64_t)Q > total) {
+        return TQ_ERR_INVALID_ARG;
+    }
+    unrank_host(ranks, first_rank, Q, (int32_t)T, quartets);
+    return TQ_OK;
+}
+
 int tq_qmc_tree(const uint32_t *splits, const double *weights, int64_t n, int64_t ntaxa, uint64_t seed, char *out,
                 int64_t cap, int64_t *written)
 {

@@ -191,6 +191,15 @@ class ShardedResolver:
                                    torch.cuda.current_stream(self.dev).cuda_stream)
         self.q_local = None
 
+    def quartet_buffer(self):
+        """The rank's device quartet buffer int32[n_local,4] (allocated on first use), for producers that fill
+        it on the device themselves (the replicate loop: unranking or the device sampler)."""
+        if self.engine is None:
+            raise ValueError("quartet_buffer needs the device path")
+        if self.d_q is None or self.d_q.shape[0] < max(1, self.n_local):
+            self.d_q = self.torch.empty((max(1, self.n_local), 4), dtype=self.torch.int32, device=self.dev)
+        return self.d_q
+
     # -- one batch -------------------------------------------------------------------------------
     def _wants_host(self) -> bool:
         return self.dst is None or self.dst == self.rank

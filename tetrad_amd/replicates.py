@@ -70,7 +70,7 @@ class ReplicateRunner:
         self._d_all = torch.empty((self.Q, 4), dtype=torch.int32, device=self.dev) if sampler == "device" else None
         self._local_index = torch.from_numpy(self.res.plan.local_index(self.res.rank)).to(self.dev) \
             if sampler == "device" else None
-        self.res.d_q = torch.empty((n, 4), dtype=torch.int32, device=self.dev)
+        self._d_q = self.res.quartet_buffer()
 
     # -- the draws of one replicate, in the reference's order ---------------------------------------------
     def _draw(self):
@@ -137,11 +137,11 @@ class ReplicateRunner:
                     if self.sampler == "host":
                         self._d_ranks.copy_(torch.from_numpy(sample), non_blocking=True)
                         keep = sample                                           # alive until the copy has run
-                        eng.unrank_dev(self._d_ranks.data_ptr(), self.n_local, res.d_q.data_ptr(), cur.cuda_stream)
+                        eng.unrank_dev(self._d_ranks.data_ptr(), self.n_local, self._d_q.data_ptr(), cur.cuda_stream)
                     else:
                         keep = None
                         eng.sample_quartets_dev(sample, self.Q, self._d_all.data_ptr(), 0, cur.cuda_stream)
-                        torch.index_select(self._d_all, 0, self._local_index, out=res.d_q)
+                        torch.index_select(self._d_all, 0, self._local_index, out=self._d_q)
                 b = k & 1
                 res.start(subsample_snps, b)
                 res.sets[b]["keep"] = keep

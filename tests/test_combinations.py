@@ -10,18 +10,14 @@ from tetrad_amd import combinations as C
 from tetrad_amd import synth
 
 
-def _index_to_combination(index, n):
-    """what combinations.py:94-106 computes, spelled out for the test (k = 4)"""
-    out = []
-    for i in range(n):
-        if len(out) == 4:
-            break
-        block = comb(n - i - 1, 4 - len(out) - 1)
-        if block > index:
-            out.append(i)
-        else:
-            index -= block
-    return tuple(out)
+def _rank_of(q, n):
+    """lexicographic rank of a sorted 4-tuple among the 4-combinations of range(n) (combinatorial number system):
+    the inverse map, computed independently of any unranker"""
+    a, b, c, d = (int(x) for x in q)
+    r = sum(comb(n - x - 1, 3) for x in range(a))
+    r += sum(comb(n - x - 1, 2) for x in range(a + 1, b))
+    r += sum(comb(n - x - 1, 1) for x in range(b + 1, c))
+    return r + (d - c - 1)
 
 
 @pytest.mark.parametrize("n", [4, 5, 9, 16])
@@ -38,7 +34,8 @@ def test_unrank_random_ranks_large_t():
     for n in (64, 256, 1700):
         r = rng.choice(comb(n, 4), size=300, replace=False)
         got = C.unrank(r, n)
-        np.testing.assert_array_equal(got, np.array([_index_to_combination(int(i), n) for i in r], np.uint32))
+        assert (np.diff(got.astype(np.int64), axis=1) > 0).all() and got.max() < n
+        assert [_rank_of(q, n) for q in got] == [int(i) for i in r]
         np.testing.assert_array_equal(got, synth.unrank_quartets(r, n))
         # first and last combination
     np.testing.assert_array_equal(C.unrank([0, comb(256, 4) - 1], 256), [[0, 1, 2, 3], [252, 253, 254, 255]])
@@ -52,7 +49,8 @@ def test_random_sample_makes_the_reference_draw():
     a, b = np.random.default_rng(5), np.random.default_rng(5)
     q = C.random_combination_sample_via_index(40, 500, a)
     idx = b.choice(comb(40, 4), size=500, replace=False)
-    np.testing.assert_array_equal(q, np.array([_index_to_combination(int(i), 40) for i in idx], np.uint32))
+    allq = np.array(list(combinations(range(40), 4)), np.uint32)
+    np.testing.assert_array_equal(q, allq[idx])
     assert a.bit_generator.state == b.bit_generator.state
     chunks = list(C.iter_chunks_random(40, 500, 128, np.random.default_rng(5)))
     assert [len(c) for c in chunks] == [128, 128, 128, 116]

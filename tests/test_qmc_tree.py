@@ -171,3 +171,12 @@ def test_file_mirror_and_array_entry(tmp_path):
     for weights in (0, 1, 2, 3):
         nwk = qmc.infer_supertree_from_arrays(quartets, rscor, rstat, T, weights=weights)
         assert _bipartitions_from_newick(nwk, T) == truth
+
+
+def test_relabel_tree():
+    nwk = "((0,1),(2,3),(4,10));"
+    names = {0: "a", 1: "b b", 2: "c", 3: "d", 4: "e", 10: "taxon_10"}
+    assert qmc.relabel_tree(nwk, names) == "((a,'b b'),(c,d),(e,taxon_10));"
+    assert qmc.relabel_tree("(0,1,2);", ["x", "y", "z"]) == "(x,y,z);"
+    with pytest.raises(KeyError):
+        qmc.relabel_tree("(0,1,7);", ["x", "y", "z"])

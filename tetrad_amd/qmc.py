@@ -69,3 +69,21 @@ def infer_supertree_from_arrays(rqrts, rscor, rstat, ntaxa: int, weights: int = 
     from .qmc_format import qmc_lines
     splits, w = parse_qmc_lines(qmc_lines(rqrts, rscor, rstat, weights, min_snps, min_ratio))
     return qmc_tree(splits, w if weights else None, ntaxa, seed)
+
+
+def relabel_tree(newick: str, samples) -> str:
+    """The tree with the numeric tip labels replaced by sample names -- what run_inference.py:169-181 does with
+    toytree.  `samples` maps the taxon number to its name (a dict, or a sequence indexed by taxon number)."""
+    import re
+    names = samples if hasattr(samples, "get") else dict(enumerate(samples))
+
+    def sub(m):
+        name = names.get(int(m.group(2)))
+        if name is None:
+            raise KeyError(f"no sample name for taxon {m.group(2)}")
+        name = str(name)
+        if re.search(r"[\s(),:;\[\]']", name):
+            name = "'" + name.replace("'", "''") + "'"
+        return m.group(1) + name
+
+    return re.sub(r"([(,])(\d+)(?=[,):])", sub, newick)

@@ -224,3 +224,19 @@ def test_kernel_level_mirrors(case):
         assert got.dtype == np.uint32 and got.shape == (3, 16, 16)
         np.testing.assert_array_equal(got, g["sub_cmats"][qi])
         np.testing.assert_array_equal(RQ.full_chunk_to_matrices(seqs, tmpmap[:, 0], mask), g["full_cmats"][qi])
+
+
+def test_end_to_end_engine_rows_to_supertree(engine):
+    """Data simulated on a known tree -> engine (all quartets) -> wQMC lines -> clean-room QMC: the generating tree
+    comes back, for 16 taxa (c1) and for 40 taxa with a sampled quartet set."""
+    from tetrad_amd import qmc, synth
+    from test_qmc_tree import _bipartitions_from_children, _bipartitions_from_newick
+    for T, S, seed, nq in ((16, 5000, synth.CONFIG_SEEDS["c1"], None), (40, 20000, 77, 40_000)):
+        tmparr, tmpmap = synth.simulate_tmparr(T, S, seed)
+        children, root = synth.random_tree_children(T, np.random.default_rng(seed))
+        q = synth.all_quartets(T) if nq is None else synth.random_quartets(T, nq, seed=3)
+        engine.set_data(tmparr, tmpmap)
+        rstat, rscor, flags = engine.resolve(q, True)
+        nwk = qmc.infer_supertree_from_arrays(q, rscor, rstat, T, weights=1)
+        truth, got = _bipartitions_from_children(children, root, T), _bipartitions_from_newick(nwk, T)
+        assert len(got & truth) >= len(truth) - (0 if T == 16 else 2), (len(got & truth), len(truth))

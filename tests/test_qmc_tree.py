@@ -180,3 +180,16 @@ def test_relabel_tree():
     assert qmc.relabel_tree("(0,1,2);", ["x", "y", "z"]) == "(x,y,z);"
     with pytest.raises(KeyError):
         qmc.relabel_tree("(0,1,7);", ["x", "y", "z"])
+
+
+@pytest.mark.parametrize("mode", ["sub", "full"])
+@pytest.mark.parametrize("weights", [0, 1, 2, 3])
+def test_end_to_end_from_the_reference_rows_of_c1(mode, weights):
+    """BASELINE.json configs[0] end to end: the REFERENCE's own rows for all 1 820 quartets of the c1 data
+    (tests/golden/c1_T16_S5000.npz) -> wQMC lines (tq_format_qmc) -> tq_qmc_tree recovers the tree the data were
+    simulated on, for every weight strategy of run_inference.py:280-297."""
+    from conftest import load_golden
+    g = load_golden("c1_T16_S5000")
+    children, root = synth.random_tree_children(16, np.random.default_rng(synth.CONFIG_SEEDS["c1"]))   # simulate_tmparr's tree
+    nwk = qmc.infer_supertree_from_arrays(g["quartets"], g[f"{mode}_rscor"], g[f"{mode}_rstat"], 16, weights=weights)
+    assert _bipartitions_from_newick(nwk, 16) == _bipartitions_from_children(children, root, 16)

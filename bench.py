@@ -145,8 +145,10 @@ def kernel_rooflines(kms: dict, calls: int, Q: int, S: int, sub: bool, cfg: str)
                         frac=None))
     if per.get("scan", 0) > 0:
         ach = scan_bytes / (per["scan"] / 1e3) / 1e9
-        out.append(dict(name="tq_scan_wg_kernel", ms=per["scan"], bound="l2->cu fabric", achieved=ach,
-                        peak=L2_TO_CU_PEAK_GBS, unit="GB/s", frac=ach / L2_TO_CU_PEAK_GBS,
+        out.append(dict(name="tq_scan_wg_kernel", ms=per["scan"],
+                        bound="co-bound: l2->cu fabric (this model), LDS pipe and VALU issue (pmc shares below); cutting the "
+                              "bytes by 40 % made it slower (DESIGN.md 4.1)",
+                        achieved=ach, peak=L2_TO_CU_PEAK_GBS, unit="GB/s", frac=ach / L2_TO_CU_PEAK_GBS,
                         model="4.4 KiB per quartet-step through the L2->CU path"))
     if per.get("bidiag", 0) > 0:
         fl = 3 * Q * (8.0 / 3.0) * 16 ** 3

@@ -37,7 +37,8 @@ while time.time() < t_end:
         q = q[np.lexsort((q[:, 3], q[:, 2], q[:, 1], q[:, 0]))]
     opts = {"scan_wg": int(rng.choice([0, 0, 1, 2, 8])), "batch": int(rng.choice([0, 0, 700])),
             "svd_method": int(rng.choice([1, 1, 0])), "xcd_remap": int(rng.integers(2)),
-            "svd_chunk": int(rng.choice([0, 0, 1, 100, 1024]))}
+            "svd_chunk": int(rng.choice([0, 0, 1, 100, 1024])), "svd_streams": int(rng.choice([0, 0, 1])),
+            "share_c": int(rng.choice([0, 0, 1]))}
     for k, v in opts.items():
         eng.set_option(k, v)
     eng.set_data(tmparr, tmpmap)

@@ -5,6 +5,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 
 #include "tetrad_hip.h"
 
@@ -49,6 +50,42 @@ int main(int argc, char **argv)
     for (int64_t i = 0; i < Q; ++i)
         printf("%u\t%u\t%u\t%u\t%.6f\t%.6f\t%.6f\t%u\t%u\n", quartets[4 * i], quartets[4 * i + 1], quartets[4 * i + 2],
                quartets[4 * i + 3], rscor[3 * i], rscor[3 * i + 1], rscor[3 * i + 2], rstat[2 * i], rstat[2 * i + 1]);
+    /* the same call with page-locked result arrays from the library's pool (written by the copy engine directly) */
+    uint32_t *p_rstat = NULL;
+    double *p_rscor = NULL;
+    if (tq_host_alloc(Q * 8, (void **)&p_rstat) || tq_host_alloc(Q * 24, (void **)&p_rscor)) return 3;
+    rc = tq_resolve(ctx, quartets, Q, subsample, p_rstat, p_rscor, NULL);
+    if (rc || memcmp(p_rstat, rstat, (size_t)Q * 8) || memcmp(p_rscor, rscor, (size_t)Q * 24)) {
+        fprintf(stderr, "pinned result arrays differ (rc=%d)\n", rc);
+        return 4;
+    }
+    tq_host_free(p_rstat);
+    tq_host_free(p_rscor);
+    /* the consumers after the hot path, natively: wQMC lines (weights strategy 1) and the quartet supertree */
+    {
+        int64_t written = 0, nlines = 0, cap = 64 * Q + 4096;
+        char *text = malloc((size_t)cap);
+        rc = tq_format_qmc(quartets, rstat, rscor, Q, 1, 0, 1.0, text, cap, &written, &nlines);
+        if (rc) return 5;
+        uint32_t *splits = malloc((size_t)nlines * 16);
+        double *w = malloc((size_t)nlines * 8);
+        const char *c = text;
+        for (int64_t i = 0; i < nlines; ++i) {                    /* "a,b|c,d:weight\n" */
+            unsigned a, b, cc, d;
+            double wt;
+            int used = 0;
+            if (sscanf(c, "%u,%u|%u,%u:%lf%n", &a, &b, &cc, &d, &wt, &used) != 5) return 6;
+            splits[4 * i] = a; splits[4 * i + 1] = b; splits[4 * i + 2] = cc; splits[4 * i + 3] = d;
+            w[i] = wt;
+            c += used + 1;
+        }
+        char nwk[1024];
+        rc = tq_qmc_tree(splits, w, nlines, T, 7, nwk, sizeof nwk - 1, &written);
+        if (rc) return 7;
+        nwk[written] = 0;
+        fprintf(stderr, "tree: %s (%lld weighted quartets)\n", nwk, (long long)nlines);
+        free(text); free(splits); free(w);
+    }
     /* error path: a taxon index out of range must be refused with a message, not crash */
     quartets[3] = 99;
     rc = tq_resolve(ctx, quartets, 1, subsample, rstat, rscor, flags);

@@ -43,6 +43,9 @@ def test_c_host_matches_oracle(tmp_path, oracle, sub):
     out = subprocess.run([str(exe), str(sub)], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stderr
     assert "rc=-1" in out.stderr                       # the bad-index call was refused with TQ_ERR_INVALID_ARG
+    tree = [ln for ln in out.stderr.splitlines() if ln.startswith("tree: ")]
+    assert len(tree) == 1 and tree[0].split()[1].endswith(";")      # wQMC lines + supertree from plain C
+    assert sorted(int(x) for x in __import__("re").findall(r"\d+", tree[0].split()[1])) == list(range(9))
     tmparr, tmpmap = make_input()
     q = synth.all_quartets(9)
     _, rstat, rscor, dbg = oracle.new_infer_resolved_quartets(tmparr, tmpmap, q, bool(sub), debug=True)

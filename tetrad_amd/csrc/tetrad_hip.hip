@@ -617,7 +617,10 @@ int stage_svd(tq_ctx *ctx, int64_t q0, int64_t n, bool debug, const OutPtrs &out
     if (q0 < 0 || n < 0 || q0 + n > ctx->scanned_Q)
         return fail(ctx, TQ_ERR_INVALID_ARG, "rows [%lld,+%lld) are outside the scanned batch of %lld quartets",
                     (long long)q0, (long long)n, (long long)ctx->scanned_Q);
-    const int64_t chunk = ctx->svd_chunk < n ? ctx->svd_chunk : n;
+    int64_t chunk = ctx->svd_chunk < n ? ctx->svd_chunk : n;
+    // a mid-size batch that would be one chunk is cut in two halves, one per stream: their tails fill each other
+    // (125k quartets 1.58 -> 1.53 ms, 300k 3.45 -> 3.35 ms) and the host API gets a result piece to copy early
+    if (ctx->svd_streams > 1 && n >= 65536 && n < 2 * ctx->svd_chunk && chunk > (n + 1) / 2) chunk = (n + 1) / 2;
     int rc = ensure_svd(ctx, chunk);
     if (rc) return rc;
     const bool two = ctx->svd_streams > 1 && n > chunk;

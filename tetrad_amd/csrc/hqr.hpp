@@ -278,9 +278,14 @@ tq_bdsqr_kernel(const double *__restrict__ de, int64_t nmat, double *__restrict_
             double g = E_(nm);
             double h = E_(k);
             const double z = W_(k);
-            double f = ((y - z) * (y + z) + (g - h) * (g + h)) * rcp_nr<2>(2.0 * h * y);
-            g = hypot_nr(f, 1.0);
-            f = ((x - z) * (x + z) + h * (y * rcp_nr<2>(f + copysign(g, f)) - h)) * rcp_nr<2>(x);
+            // the shift only steers convergence (any shift gives an orthogonal sweep), so its three reciprocals and
+            // its square root need no more than one Newton step (~1e-15)
+            double f = ((y - z) * (y + z) + (g - h) * (g + h)) * rcp_nr<1>(2.0 * h * y);
+            {
+                const double t2 = fma(f, f, 1.0);
+                g = t2 * rsq_nr<1>(t2);
+            }
+            f = ((x - z) * (x + z) + h * (y * rcp_nr<1>(f + copysign(g, f)) - h)) * rcp_nr<1>(x);
             double cc = 1.0, ss = 1.0;
             // one QR sweep over the block [l,k]; the LDS reads of the next step are issued before the
             // current step's arithmetic, each hypot shares one rsq with the reciprocal its rotation

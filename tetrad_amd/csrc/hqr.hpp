@@ -50,9 +50,11 @@ __device__ __forceinline__ double quad_sum(double v)
 
 __device__ __forceinline__ double sqrt_nr(double x)     // x >= 0, full precision, sqrt(0) = 0
 {
-    const double y = rsq_nr<2>(x);
+    // v_rsq_f64 (5e-8) + one Newton step (4e-15), then one Heron step on the root itself, which squares that
+    // error: full precision without a second Newton step on the reciprocal root
+    const double y = rsq_nr<1>(x);
     const double s = x * y;
-    const double r = fma(fma(-s, s, x), 0.5 * y, s);     // one more correction on the root itself
+    const double r = fma(fma(-s, s, x), 0.5 * y, s);
     return x > 0.0 ? r : 0.0;
 }
 
@@ -141,7 +143,10 @@ tq_bidiag_kernel(const uint32_t *__restrict__ cm, int64_t Q, double *__restrict_
                     const double alpha = live ? ((x0 < 0.0) ? nrm : -nrm) : 0.0;
                     v[K] = x0 - alpha;
                     const double den = fma(-alpha, x0, n2);      // = |v|^2 / 2 > 0 for a live column
-                    const double beta = live ? rcp_nr<2>(den) : 0.0;
+                    // one Newton step (2e-15) is enough: I - beta(1+d) v v^T is the exact reflector times a scaling
+                    // of ONE direction by 1+2d -- invertible, so ranks and zero singular values are untouched and the
+                    // others move by a relative 4e-15
+                    const double beta = live ? rcp_nr<1>(den) : 0.0;
                     if (writer) dout[K] = alpha;
 #pragma unroll
                     for (int s = so; s < 4; ++s) {
@@ -170,7 +175,7 @@ tq_bidiag_kernel(const uint32_t *__restrict__ cm, int64_t Q, double *__restrict_
                     const double nrm = sqrt_nr(n2);
                     const double alpha = live ? ((x0 < 0.0) ? nrm : -nrm) : 0.0;
                     const double den = fma(-alpha, x0, n2);
-                    const double beta = live ? rcp_nr<2>(den) : 0.0;
+                    const double beta = live ? rcp_nr<1>(den) : 0.0;
                     if (c == c1) y[s1] = x0 - alpha;
                     if (writer) dout[16 + K1] = alpha;
 #pragma unroll

@@ -95,6 +95,7 @@ tq_bidiag_kernel(const uint32_t *__restrict__ cm, int64_t Q, double *__restrict_
             s += __shfl_xor(s, 2, WAVE);
             if (c == 0 && myq < Q) nsnps_out[myq] = s;
         }
+        double thr2 = 0.0;                                      // set at t = 0: ||M_t||_F is the same for all three
 #pragma unroll 1
         for (int t = 0; t < 3; ++t) {
             double a[4][16];                                    // a[s][r] = M_t[r][4s + c]
@@ -114,13 +115,16 @@ tq_bidiag_kernel(const uint32_t *__restrict__ cm, int64_t Q, double *__restrict_
             // (~1e-17) is "reflected", the next one shrinks to ~1e-33, ... and after ten such
             // columns the squared norms reach the denormal range, 1/den overflows and the rest of
             // the matrix is destroyed (found by the sparse-data stress test against the Jacobi path).
-            double f2 = 0.0;
+            // (the three flattenings hold the same 256 counts, so their Frobenius norms agree: once per quartet)
+            if (t == 0) {
+                double f2 = 0.0;
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {
+                for (int s = 0; s < 4; ++s) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) f2 = fma(a[s][r], a[s][r], f2);
+                    for (int r = 0; r < 16; ++r) f2 = fma(a[s][r], a[s][r], f2);
+                }
+                thr2 = quad_sum(f2) * 1e-40;
             }
-            const double thr2 = quad_sum(f2) * 1e-40;
             // d[K] / e[K] are stored as soon as they are known (keeping 32 more f64 live would cost
             // the kernel its second wave per SIMD)
             double *dout = de + (myq * 3 + t) * 32;
@@ -178,12 +182,15 @@ tq_bidiag_kernel(const uint32_t *__restrict__ cm, int64_t Q, double *__restrict_
                     const double beta = live ? rcp_nr<1>(den) : 0.0;
                     if (c == c1) y[s1] = x0 - alpha;
                     if (writer) dout[16 + K1] = alpha;
+                    double yb[4];                                // beta * y: one multiply per slot instead of one per row
+#pragma unroll
+                    for (int s = sb; s < 4; ++s) yb[s] = beta * y[s];
 #pragma unroll
                     for (int i = K1; i < 16; ++i) {
                         double q = 0.0;
 #pragma unroll
-                        for (int s = sb; s < 4; ++s) q = fma(y[s], a[s][i], q);
-                        const double tt = beta * quad_sum(q);
+                        for (int s = sb; s < 4; ++s) q = fma(yb[s], a[s][i], q);
+                        const double tt = quad_sum(q);
 #pragma unroll
                         for (int s = sb; s < 4; ++s) a[s][i] = fma(-tt, y[s], a[s][i]);
                     }

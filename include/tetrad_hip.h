@@ -231,6 +231,13 @@ int tq_format_qmc(const uint32_t *quartets, const uint32_t *rstat, const double 
                   int weights, int64_t min_snps, double min_ratio, char *out, int64_t cap,
                   int64_t *written, int64_t *n_lines);
 
+/* The reference's quartet sample, stream-identical and faster (host code): what
+ * `Generator.choice(pop, size, replace=False)` (combinations.py:113) returns when size > pop // 50 and
+ * pop > 10 000 -- NumPy's tail shuffle of arange(pop) -- drawn from the SAME NumPy bit generator, passed as the
+ * address NumPy publishes in `rng.bit_generator.ctypes.bit_generator` (caller holds `bit_generator.lock`).
+ * The Generator is left in the state NumPy's own call would leave it in.  pop <= 2^32 - 2.        */
+int tq_numpy_choice_tail(void *np_bitgen, uint64_t pop, int64_t size, int64_t *out);
+
 /* Lexicographic unranking on the host (no device involved): quartets[i] = the 4-combination of range(T) with
  * rank ranks[i] (or first_rank + i when ranks is NULL), i.e. _index_to_combination (combinations.py:94-106) for
  * every sampled index / islice(combinations(range(T), 4), first_rank, first_rank + Q) (combinations.py:40-55).

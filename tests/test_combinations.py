@@ -63,3 +63,34 @@ def test_unrank_rejects_ranks_beyond_the_space():
         C.unrank([comb(10, 4)], 10)
     with pytest.raises(TetradHipError):
         C.unrank(None, 10, comb(10, 4) - 1, 2)
+
+
+@pytest.mark.parametrize("pop,size", [(10_001, 201), (10_001, 10_001), (20_001, 20_000), (65_537, 1_400), (123_457, 40_000),
+                                      (635_376, 100_000), (2_000_003, 40_001), (10_668_000, 1_000_000)])
+def test_fast_choice_is_numpys_choice_bit_for_bit(pop, size):
+    """tq_numpy_choice_tail against Generator.choice itself (NumPy's tail-shuffle regime: pop > 10 000 and
+    size > pop // 50): the same int64 sample AND the same Generator state afterwards, so that a project's random
+    stream is unchanged; two calls in a row stay in step."""
+    assert pop > 10_000 and size > pop // 50
+    for seed in (0, 12345):
+        a, b = np.random.default_rng(seed), np.random.default_rng(seed)
+        for _ in range(2):
+            want = a.choice(pop, size=size, replace=False)
+            got = C.choice_without_replacement(b, pop, size)
+            assert got.dtype == np.int64
+            np.testing.assert_array_equal(got, want)
+            assert a.bit_generator.state == b.bit_generator.state
+    assert C._fast_choice_ok is True
+
+
+def test_fast_choice_falls_back_outside_its_regime():
+    """small populations / small samples (NumPy uses Floyd's algorithm there) and other bit generators go through
+    NumPy itself: still the same sample and state"""
+    for pop, size in ((5000, 4000), (1_000_000, 100), (10_668_000, 213_360)):
+        a, b = np.random.default_rng(3), np.random.default_rng(3)
+        np.testing.assert_array_equal(C.choice_without_replacement(b, pop, size), a.choice(pop, size=size, replace=False))
+        assert a.bit_generator.state == b.bit_generator.state
+    a = np.random.Generator(np.random.Philox(9))
+    b = np.random.Generator(np.random.Philox(9))
+    np.testing.assert_array_equal(C.choice_without_replacement(b, 50_000, 20_000), a.choice(50_000, size=20_000, replace=False))
+    assert a.bit_generator.state["state"]["counter"].tolist() == b.bit_generator.state["state"]["counter"].tolist()

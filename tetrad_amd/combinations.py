@@ -36,6 +36,50 @@ def unrank(ranks=None, nsamples: int = 0, first_rank: int = 0, count: int = 0) -
     return out
 
 
+_fast_choice_ok = None
+
+
+def _fast_choice_raw(rng, pop: int, size: int, out=None):
+    from . import _lib
+    lib = _lib.load()
+    bg = rng.bit_generator
+    if out is None:
+        out = np.empty(size, np.int64)
+    with bg.lock:
+        rc = lib.tq_numpy_choice_tail(bg.ctypes.bit_generator, int(pop), int(size), out.ctypes.data)
+    if rc != 0:
+        raise _lib.TetradHipError(rc, "tq_numpy_choice_tail")
+    return out
+
+
+def choice_without_replacement(rng, pop: int, size: int, out=None) -> np.ndarray:
+    """`rng.choice(pop, size=size, replace=False)` -- the same int64 sample, the same Generator state afterwards --
+    through the library's restatement of NumPy's tail shuffle (`tq_numpy_choice_tail`: sparse map + prefetch
+    instead of an 8*pop-byte arange; about 3x faster for 1e6 of 1e7) when the call is in that regime
+    (pop > 10 000, size > pop // 50, pop < 2^32 - 1) and the restatement has just proven itself against NumPy's
+    own `Generator.choice` on this installation; NumPy's call otherwise."""
+    global _fast_choice_ok
+    pop, size = int(pop), int(size)
+    if _fast_choice_ok is None:
+        try:
+            a = np.random.Generator(np.random.PCG64(20240229))
+            b = np.random.Generator(np.random.PCG64(20240229))
+            ok = True
+            for p_, s_ in ((10_007, 201), (50_000, 50_000), (123_457, 40_000)):
+                ok &= bool(np.array_equal(a.choice(p_, size=s_, replace=False), _fast_choice_raw(b, p_, s_)))
+                ok &= a.bit_generator.state == b.bit_generator.state
+            _fast_choice_ok = bool(ok)
+        except Exception:
+            _fast_choice_ok = False
+    if _fast_choice_ok and 10_000 < pop < 0xFFFFFFFF and pop // 50 < size <= pop and isinstance(rng, np.random.Generator):
+        return _fast_choice_raw(rng, pop, size, out)
+    res = rng.choice(pop, size=size, replace=False)
+    if out is not None:
+        out[...] = res
+        return out
+    return res
+
+
 def get_chunks_info(nsamples: int, max_chunk_size: int) -> list[tuple[int, int]]:
     """combinations.py:11-37: (start, end) rank ranges of the chunks of the full enumeration."""
     total = comb(nsamples, 4)
@@ -56,7 +100,7 @@ def iter_chunks_full(nsamples: int, max_size: int):
 def random_combination_sample_via_index(nsamples: int, size: int, rng) -> np.ndarray:
     """combinations.py:109-114: one `rng.choice(C(nsamples,4), size, replace=False)`, then unranking."""
     rng = default_rng(rng)
-    return unrank(rng.choice(comb(nsamples, 4), size=size, replace=False), nsamples)
+    return unrank(choice_without_replacement(rng, comb(nsamples, 4), size), nsamples)
 
 
 def iter_chunks_random(nsamples: int, size: int, max_size: int, rng):

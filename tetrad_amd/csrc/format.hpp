@@ -171,3 +171,94 @@ inline void unrank_host(const uint64_t *ranks, uint64_t first_rank, int64_t Q, i
         memcpy(quartets + 4 * i, out, 16);
     }
 }
+
+// ------------------------------------------------------------------------------------------------------
+// The reference draws its quartet sample with `rng.choice(C(T,4), size, replace=False)` on the project's NumPy
+// Generator (combinations.py:113): 31 ms for 1e6 of 10.7e6 -- more than a bootstrap replicate's kernels -- and
+// its stream is what a reproducible run is defined by.  For samples larger than 1/50 of the population NumPy
+// (numpy/random/_generator.pyx, `Generator.choice`; third-party dependency of the reference, unpinned by it,
+// 2.2.6 here) shuffles the TAIL of arange(pop): for i = pop-1 down to pop-size it swaps position i with a
+// position j drawn uniformly from [0, i] by Lemire's multiply-shift rejection on 32-bit draws, then returns
+// positions pop-size .. pop-1.  This function makes THE SAME draws from the SAME bit generator (through the
+// function pointers NumPy publishes as `bit_generator.ctypes`) and applies the same swaps -- on a sparse map of
+// the positions touched instead of an 8*pop-byte array, with the map slots of the next draws prefetched -- so
+// it returns NumPy's sample and leaves the Generator in NumPy's state.  tetrad_amd/combinations.py checks it
+// against `Generator.choice` itself before trusting it (and tests/test_combinations.py for many shapes).
+// ------------------------------------------------------------------------------------------------------
+struct NpBitgen {                 // numpy/random/bitgen.h: bitgen_t
+    void *state;
+    uint64_t (*next_uint64)(void *);
+    uint32_t (*next_uint32)(void *);
+    double (*next_double)(void *);
+    uint64_t (*next_raw)(void *);
+};
+
+inline uint32_t np_bounded_lemire_u32(NpBitgen *bg, uint32_t rng)        // uniform on [0, rng], rng < 2^32 - 1
+{
+    const uint32_t rng_excl = rng + 1u;
+    uint64_t m = (uint64_t)bg->next_uint32(bg->state) * rng_excl;
+    uint32_t leftover = (uint32_t)m;
+    if (leftover < rng_excl) {
+        const uint32_t threshold = (0xFFFFFFFFu - rng) % rng_excl;
+        while (leftover < threshold) {
+            m = (uint64_t)bg->next_uint32(bg->state) * rng_excl;
+            leftover = (uint32_t)m;
+        }
+    }
+    return (uint32_t)(m >> 32);
+}
+
+// out[k] = value that ends at position (pop - size + k) of the tail-shuffled arange(pop); pop <= 2^32 - 2.
+// Positions >= pop - size (the part that is returned) live in `out` itself; positions below it are only ever the
+// target `j` of a swap and live in a sparse open-addressing map (one 8-byte slot = position+1 in the high half,
+// value in the low half).  The draws of the next 32 swaps are made ahead and their slots prefetched.
+inline int numpy_choice_tail(NpBitgen *bg, uint64_t pop, int64_t size, int64_t *out)
+{
+    const uint64_t base = pop - (uint64_t)size;                                     // first returned position
+    const uint64_t first = base > 1 ? base : 1;                                     // max(pop - size, 1)
+    const uint64_t count = pop - first;                                             // swaps to make
+    for (int64_t k = 0; k < size; ++k) out[k] = (int64_t)(base + (uint64_t)k);      // arange, tail part
+    uint64_t cap = 1024;
+    while (cap < 2 * count) cap <<= 1;
+    const uint64_t mask = cap - 1;
+    static thread_local std::vector<uint64_t> head;
+    try {
+        head.assign((size_t)cap, 0ull);
+    } catch (const std::bad_alloc &) {
+        return TQ_ERR_OOM;
+    }
+    uint64_t *slots = head.data();
+    auto home = [mask](uint64_t pos) { return ((pos * 0x9E3779B97F4A7C15ull) >> 24) & mask; };
+    constexpr int B = 32;
+    uint32_t jb[B];
+    uint64_t i = pop - 1, left = count;
+    while (left) {
+        const int nb = left < (uint64_t)B ? (int)left : B;
+        for (int b = 0; b < nb; ++b) {
+            const uint32_t j = np_bounded_lemire_u32(bg, (uint32_t)(i - (uint64_t)b));
+            jb[b] = j;
+            if (j >= base) __builtin_prefetch(&out[j - base], 1);
+            else __builtin_prefetch(&slots[home(j)], 1);
+        }
+        for (int b = 0; b < nb; ++b, --i) {
+            const uint64_t j = jb[b];
+            const uint64_t vi = (uint64_t)out[i - base];          // i >= first >= base always
+            uint64_t vj;
+            if (j >= base) {                                      // both in the returned part
+                vj = (uint64_t)out[j - base];
+                out[j - base] = (int64_t)vi;
+            } else {
+                uint64_t h = home(j);
+                const uint64_t key = (j + 1) << 32;
+                while (slots[h] != 0 && (slots[h] & 0xFFFFFFFF00000000ull) != key) h = (h + 1) & mask;
+                vj = slots[h] ? (slots[h] & 0xFFFFFFFFull) : j;
+                slots[h] = key | vi;                              // data[j] = data[i]
+            }
+            out[i - base] = (int64_t)vj;                          // data[i] = data[j]
+        }
+        left -= (uint64_t)nb;
+    }
+    // size == pop: base = 0, position 0 is part of `out` and was handled as a `j` target; nothing left to do
+    if (head.capacity() > ((size_t)1 << 25)) std::vector<uint64_t>().swap(head);   // do not sit on > 256 MB
+    return TQ_OK;
+}

@@ -1548,6 +1548,12 @@ int tq_format_qmc(const uint32_t *quartets, const uint32_t *rstat, const double 
     return n < 0 ? TQ_ERR_OOM : TQ_OK;
 }
 
+int tq_numpy_choice_tail(void *np_bitgen, uint64_t pop, int64_t size, int64_t *out)
+{
+    if (!np_bitgen || !out || size < 1 || (uint64_t)size > pop || pop < 2 || pop > 0xFFFFFFFEull) return TQ_ERR_INVALID_ARG;
+    return numpy_choice_tail((NpBitgen *)np_bitgen, pop, size, out);
+}
+
 int tq_unrank(const uint64_t *ranks, uint64_t first_rank, int64_t Q, int64_t T, uint32_t *quartets)
 {
     if (Q < 0 || T < 4 || T > 100000 || (Q > 0 && !quartets)) return TQ_ERR_INVALID_ARG;     // C(T,4) must fit 64 bits

@@ -244,6 +244,11 @@ int tq_numpy_choice_tail(void *np_bitgen, uint64_t pop, int64_t size, int64_t *o
  * TQ_ERR_INVALID_ARG when a rank is >= C(T,4).                                                     */
 int tq_unrank(const uint64_t *ranks, uint64_t first_rank, int64_t Q, int64_t T, uint32_t *quartets);
 
+/* The rows tq_format_qmc would write, as arrays (no text round trip): splits u32[n,4] = "a,b|c,d" and weights f64[n]
+ * (the value of the line's "%.5f" text), n = *n_rows <= Q; splits / weights must hold Q rows.  Input for tq_qmc_tree.  */
+int tq_qmc_splits(const uint32_t *quartets, const uint32_t *rstat, const double *rscor, int64_t Q, int weights,
+                  int64_t min_snps, double min_ratio, uint32_t *splits, double *weights_out, int64_t *n_rows);
+
 /* Quartet supertree (host code, no device involved): weighted Quartet MaxCut over `n` resolved quartets
  * splits u32[n,4] = "a,b|c,d" (the taxa of a wQMC input line, run_inference.py:264-305), weights f64[n] or
  * NULL (all 1), taxa 0..ntaxa-1.  Writes the unrooted tree as newick with the taxon numbers as tip labels

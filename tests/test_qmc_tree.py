@@ -193,3 +193,21 @@ def test_end_to_end_from_the_reference_rows_of_c1(mode, weights):
     children, root = synth.random_tree_children(16, np.random.default_rng(synth.CONFIG_SEEDS["c1"]))   # simulate_tmparr's tree
     nwk = qmc.infer_supertree_from_arrays(g["quartets"], g[f"{mode}_rscor"], g[f"{mode}_rstat"], 16, weights=weights)
     assert _bipartitions_from_newick(nwk, 16) == _bipartitions_from_children(children, root, 16)
+
+
+@pytest.mark.parametrize("weights", [0, 1, 2, 3])
+@pytest.mark.parametrize("min_snps,min_ratio", [(0, 1.0), (500, 1.3)])
+def test_qmc_splits_equal_the_parsed_lines(weights, min_snps, min_ratio):
+    """tq_qmc_splits (arrays) == the lines of tq_format_qmc parsed back, bit for bit, incl. the "%.5f" weights"""
+    from tetrad_amd import qmc_format
+    rng = np.random.default_rng(weights)
+    n = 4000
+    q = np.sort(rng.integers(0, 60, size=(n, 4)), axis=1).astype(np.uint32)
+    sc = rng.gamma(2.0, 20.0, size=(n, 3))
+    sc[::37] = 0.001
+    sc[5::101, 0] = 0.0
+    st = np.stack([rng.integers(0, 3, size=n), rng.integers(0, 3000, size=n)], axis=1).astype(np.uint32)
+    sp, w = qmc.qmc_splits(q, sc, st, weights, min_snps, min_ratio)
+    sp2, w2 = qmc.parse_qmc_lines(qmc_format.qmc_lines(q, sc, st, weights, min_snps, min_ratio))
+    np.testing.assert_array_equal(sp, sp2)
+    np.testing.assert_array_equal(w, w2)

@@ -32,7 +32,7 @@ SYMBOLS = [
     "tq_resolve_dev", "tq_resolve_range_dev", "tq_unrank_dev", "tq_resolve_debug",
     "tq_timing_enable", "tq_timing_read", "tq_timing_read_split", "tq_timing_read_kernels",
     "tq_set_option", "tq_device_info", "tq_debug_fetch",
-    "tq_format_tsv", "tq_format_qmc", "tq_qmc_tree", "tq_unrank", "tq_numpy_choice_tail",
+    "tq_format_tsv", "tq_format_qmc", "tq_qmc_tree", "tq_qmc_splits", "tq_unrank", "tq_numpy_choice_tail",
 ]
 
 
@@ -149,6 +149,8 @@ def load() -> ctypes.CDLL:
     lib.tq_format_tsv.restype = i32
     lib.tq_format_qmc.argtypes = [vp, vp, vp, i64, i32, i64, c.c_double, vp, i64, c.POINTER(i64), c.POINTER(i64)]
     lib.tq_format_qmc.restype = i32
+    lib.tq_qmc_splits.argtypes = [vp, vp, vp, i64, i32, i64, c.c_double, vp, vp, c.POINTER(i64)]
+    lib.tq_qmc_splits.restype = i32
     lib.tq_numpy_choice_tail.argtypes = [vp, c.c_uint64, i64, vp]
     lib.tq_numpy_choice_tail.restype = i32
     lib.tq_unrank.argtypes = [vp, c.c_uint64, i64, i64, vp]

@@ -80,13 +80,72 @@ inline int64_t format_tsv(const uint32_t *quartets, const uint32_t *rstat, const
     return p - out;
 }
 
-// the value the reference reads back from the TSV: the score rounded to 6 decimals as text
-inline double reread6(double x)
+// The double a reader gets back from the text of x with `dec` decimals ("%.<dec>f" then float()): away from a
+// rounding tie that is the integer nearest to x * 10^dec, divided by 10^dec -- one correctly rounded division of two
+// exactly representable numbers, hence the double nearest to the decimal string, which is what strtod returns; near
+// a tie (or out of range) the text is actually produced and parsed.
+inline double reread_dec(double x, int dec)
 {
+    static const double P10[10] = {1e0, 1e1, 1e2, 1e3, 1e4, 1e5, 1e6, 1e7, 1e8, 1e9};
+    if (x >= 0.0 && x < 4.0e9 && dec >= 0 && dec <= 9) {
+        const double scaled = x * P10[dec];
+        const double fl = std::floor(scaled);
+        const double frac = scaled - fl;
+        if (std::fabs(frac - 0.5) > 2e-6 && scaled < 4.0e9) return (fl + (frac > 0.5 ? 1.0 : 0.0)) / P10[dec];
+    }
     char buf[400];
-    char *e = put_fixed(buf, x, 6);
+    char *e = put_fixed(buf, x, dec);
     *e = 0;
     return strtod(buf, nullptr);
+}
+
+// the value the reference reads back from the TSV: the score rounded to 6 decimals as text
+inline double reread6(double x) { return reread_dec(x, 6); }
+
+// One row of the quartets table -> does it pass min_snps / min_ratio (run_inference.py:258,275,300), which split does
+// its topology mean (:264-270) and what is its weight (:280-297, from the scores as they read back from the TSV).
+inline bool qmc_row(const uint32_t *q, uint32_t order, uint32_t nsnps, const double *sc, int weights, int64_t min_snps,
+                    double min_ratio, uint32_t (&split)[4], double &weight)
+{
+    if ((int64_t)nsnps < min_snps) return false;                      // :275
+    weight = 1.0;
+    double ratio = 1.0;
+    if (weights) {                                                    // :284-297
+        double s[3] = {reread6(sc[0]), reread6(sc[1]), reread6(sc[2])};
+        if (s[0] > s[1]) std::swap(s[0], s[1]);
+        if (s[1] > s[2]) std::swap(s[1], s[2]);
+        if (s[0] > s[1]) std::swap(s[0], s[1]);
+        const double smean = (s[1] + s[2]) / 2.0;                     // numpy mean of two values
+        const double smin = s[0];
+        ratio = smin == 0.0 ? 1.0 : smean / smin;
+        if (weights == 1) weight = smean;
+        else if (weights == 2) weight = ratio;
+        else weight = 1.0 - smin / ((s[0] + s[1]) + s[2]);            // numpy sum, left to right
+    }
+    if (ratio < min_ratio) return false;                              // :300
+    split[0] = q[0]; split[1] = q[1]; split[2] = q[2]; split[3] = q[3];
+    if (order == 1) { split[1] = q[2]; split[2] = q[1]; }             // a,c|b,d
+    else if (order == 2) { split[1] = q[3]; split[2] = q[1]; split[3] = q[2]; }   // a,d|b,c
+    return true;
+}
+
+// the same rows as arrays: splits u32[n,4] = a,b|c,d and the weights as the wQMC input file would carry them
+// ("%.5f" text read back); returns the number of rows kept
+inline int64_t qmc_splits(const uint32_t *quartets, const uint32_t *rstat, const double *rscor, int64_t Q, int weights,
+                          int64_t min_snps, double min_ratio, uint32_t *splits, double *wout)
+{
+    if (min_snps < 1) min_snps = 1;                                   // :258
+    int64_t n = 0;
+    for (int64_t i = 0; i < Q; ++i) {
+        uint32_t sp[4];
+        double w;
+        if (!qmc_row(quartets + i * 4, rstat[i * 2], rstat[i * 2 + 1], rscor + i * 3, weights, min_snps, min_ratio, sp, w))
+            continue;
+        memcpy(splits + 4 * n, sp, 16);
+        wout[n] = reread_dec(w, 5);                                   // :305 "{:.5f}"
+        ++n;
+    }
+    return n;
 }
 
 // "a,b|c,d:weight\n" lines (run_inference.py:264-305) for the rows that pass the two filters;
@@ -100,26 +159,11 @@ inline int64_t format_qmc(const uint32_t *quartets, const uint32_t *rstat, const
     int64_t lines = 0;
     for (int64_t i = 0; i < Q; ++i) {
         if (end - p < QMC_MAX_LINE) return -((p - out) + (Q - i) * QMC_MAX_LINE);
-        const uint32_t *q = quartets + i * 4;
-        const uint32_t order = rstat[i * 2], nsnps = rstat[i * 2 + 1];
-        if ((int64_t)nsnps < min_snps) continue;                      // :275
-        double weight = 1.0, ratio = 1.0;
-        if (weights) {                                                // :284-297
-            double s[3] = {reread6(rscor[i * 3]), reread6(rscor[i * 3 + 1]), reread6(rscor[i * 3 + 2])};
-            if (s[0] > s[1]) std::swap(s[0], s[1]);
-            if (s[1] > s[2]) std::swap(s[1], s[2]);
-            if (s[0] > s[1]) std::swap(s[0], s[1]);
-            const double smean = (s[1] + s[2]) / 2.0;                 // numpy mean of two values
-            const double smin = s[0];
-            ratio = smin == 0.0 ? 1.0 : smean / smin;
-            if (weights == 1) weight = smean;
-            else if (weights == 2) weight = ratio;
-            else weight = 1.0 - smin / ((s[0] + s[1]) + s[2]);        // numpy sum, left to right
-        }
-        if (ratio < min_ratio) continue;                              // :300
-        uint32_t a = q[0], b = q[1], c = q[2], d = q[3];
-        if (order == 1) { b = q[2]; c = q[1]; }                       // a,c|b,d
-        else if (order == 2) { b = q[3]; c = q[1]; d = q[2]; }        // a,d|b,c
+        uint32_t sp[4];
+        double weight;
+        if (!qmc_row(quartets + i * 4, rstat[i * 2], rstat[i * 2 + 1], rscor + i * 3, weights, min_snps, min_ratio, sp, weight))
+            continue;
+        const uint32_t a = sp[0], b = sp[1], c = sp[2], d = sp[3];
         p = put_u32(p, a); *p++ = ',';
         p = put_u32(p, b); *p++ = '|';
         p = put_u32(p, c); *p++ = ',';

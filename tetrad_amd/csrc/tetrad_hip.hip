@@ -1548,6 +1548,15 @@ int tq_format_qmc(const uint32_t *quartets, const uint32_t *rstat, const double 
     return n < 0 ? TQ_ERR_OOM : TQ_OK;
 }
 
+int tq_qmc_splits(const uint32_t *quartets, const uint32_t *rstat, const double *rscor, int64_t Q, int weights,
+                  int64_t min_snps, double min_ratio, uint32_t *splits, double *wout, int64_t *n_rows)
+{
+    if (Q < 0 || !n_rows || weights < 0 || weights > 3 || (Q > 0 && (!quartets || !rstat || !rscor || !splits || !wout)))
+        return TQ_ERR_INVALID_ARG;
+    *n_rows = qmc_splits(quartets, rstat, rscor, Q, weights, min_snps, min_ratio, splits, wout);
+    return TQ_OK;
+}
+
 int tq_numpy_choice_tail(void *np_bitgen, uint64_t pop, int64_t size, int64_t *out)
 {
     if (!np_bitgen || !out || size < 1 || (uint64_t)size > pop || pop < 2 || pop > 0xFFFFFFFEull) return TQ_ERR_INVALID_ARG;

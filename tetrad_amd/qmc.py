@@ -39,6 +39,27 @@ def qmc_tree(splits: np.ndarray, weights=None, ntaxa: int | None = None, seed: i
     raise _lib.TetradHipError(rc, "tq_qmc_tree: buffer sizing failed")
 
 
+def qmc_splits(rqrts, rscor, rstat, weights: int = 0, min_snps: int = 0, min_ratio: float = 1.0):
+    """The rows `qmc_format.qmc_lines` would write, as arrays: (splits u32[n,4], weights f64[n]) -- same filters, same
+    weight strategies, the weight as its "%.5f" text reads back -- without producing or parsing text."""
+    from . import _lib
+    lib = _lib.load()
+    if weights not in (0, 1, 2, 3):
+        raise ValueError(f"no weight strategy {weights}")
+    q = np.ascontiguousarray(rqrts, dtype=np.uint32).reshape(-1, 4)
+    st = np.ascontiguousarray(rstat, dtype=np.uint32).reshape(-1, 2)
+    sc = np.ascontiguousarray(rscor, dtype=np.float64).reshape(-1, 3)
+    n = q.shape[0]
+    sp = np.empty((n, 4), np.uint32)
+    w = np.empty(n, np.float64)
+    kept = ctypes.c_int64()
+    rc = lib.tq_qmc_splits(q.ctypes.data, st.ctypes.data, sc.ctypes.data, n, int(weights), int(min_snps), float(min_ratio),
+                           sp.ctypes.data, w.ctypes.data, ctypes.byref(kept))
+    if rc != 0:
+        raise _lib.TetradHipError(rc, "tq_qmc_splits")
+    return sp[:kept.value], w[:kept.value]
+
+
 def parse_qmc_lines(lines) -> tuple[np.ndarray, np.ndarray]:
     """"a,b|c,d:w" lines (run_inference.py:305) -> (splits u32[n,4], weights f64[n])."""
     sp, w = [], []
@@ -66,8 +87,7 @@ def infer_supertree_from_arrays(rqrts, rscor, rstat, ntaxa: int, weights: int = 
                                 min_ratio: float = 1.0, seed: int = 0) -> str:
     """run_inference.py:330-357 straight from the result arrays of a replicate: the wQMC lines of
     `tq_format_qmc` (same filters and weight strategies as :254-305), then the tree."""
-    from .qmc_format import qmc_lines
-    splits, w = parse_qmc_lines(qmc_lines(rqrts, rscor, rstat, weights, min_snps, min_ratio))
+    splits, w = qmc_splits(rqrts, rscor, rstat, weights, min_snps, min_ratio)
     return qmc_tree(splits, w if weights else None, ntaxa, seed)
 
 

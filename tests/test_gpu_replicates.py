@@ -101,3 +101,46 @@ def test_replicate_runner_equals_step_by_step(oracle, sampler):
     # the producer may have drawn ahead, but never beyond the replicates it was asked for
     assert final_state == rng.bit_generator.state
     assert runner.rng_state_after[-1] == rng.bit_generator.state
+
+
+@pytest.mark.parametrize("sampler", ["host", "device"])
+def test_bootstrap_trees_end_to_end(sampler):
+    """run_inference.py:378-407 with the supertree step: replicates -> rows + sampled quartets on the host -> one tree per
+    replicate.  Every tree must equal the tree built step by step from the same draws, hold every taxon once, and --
+    the data being simulated on a known tree -- most replicates recover most of that tree."""
+    import torch
+    from math import comb
+    import sys
+    sys.path.insert(0, str(__import__("pathlib").Path(__file__).parent))
+    from test_qmc_tree import _bipartitions_from_children, _bipartitions_from_newick
+    from tetrad_amd import bootstrap, qmc, synth
+    from tetrad_amd.engine import QuartetEngine
+    from tetrad_amd.replicates import bootstrap_trees
+    T, S, seed = 14, 6000, 8
+    seqarr, maparr, spans = synth.make_c5_source(T=T, S=S, seed=seed, ambiguous=0.02)
+    children, root = synth.random_tree_children(T, np.random.default_rng(seed))
+    truth = _bipartitions_from_children(children, root, T)
+    Q, nboots = 800, 4
+    with QuartetEngine(0) as eng:
+        trees = bootstrap_trees(eng, seqarr, spans, Q, nboots, weights=1, seed=21, sampler=sampler, workers=2)
+    assert len(trees) == nboots
+    rng = np.random.default_rng(21)
+    dev = torch.device("cuda:0")
+    agree = []
+    with QuartetEngine(0) as eng:
+        eng.set_source(seqarr, spans)
+        for k in range(nboots):
+            lidxs, s1, s2 = bootstrap.draw_replicate(len(spans), rng)
+            eng.bootstrap(lidxs, s1, s2)
+            if sampler == "host":
+                q = synth.unrank_quartets(rng.choice(comb(T, 4), size=Q, replace=False), T)
+            else:
+                d_q = torch.empty((Q, 4), dtype=torch.int32, device=dev)
+                eng.sample_quartets_dev(int(rng.integers(2**63)), Q, d_q.data_ptr(), 0)
+                torch.cuda.synchronize()
+                q = d_q.cpu().numpy().view(np.uint32)
+            rstat, rscor, _ = eng.resolve(q, True)
+            assert trees[k] == qmc.infer_supertree_from_arrays(q, rscor, rstat, T, 1, seed=k)
+            got = _bipartitions_from_newick(trees[k], T)
+            agree.append(len(got & truth))
+    assert max(agree) >= len(truth) - 2, (agree, len(truth))

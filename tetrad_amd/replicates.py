@@ -44,7 +44,7 @@ from .engine import QuartetEngine, pinned_empty
 class ReplicateRunner:
     def __init__(self, engine: QuartetEngine, seqarr: np.ndarray, spans: np.ndarray, nquartets: int, *,
                  seed=None, rng: Optional[np.random.Generator] = None, sampler: str = "host", group=None,
-                 pieces: Optional[int] = None, dst: Optional[int] = 0, ahead: int = 3):
+                 pieces: Optional[int] = None, dst: Optional[int] = 0, ahead: int = 3, quartets_to_host: bool = False):
         import torch
         if sampler not in ("host", "device"):
             raise ValueError("sampler must be 'host' or 'device'")
@@ -74,6 +74,13 @@ class ReplicateRunner:
         self._local_index = torch.from_numpy(self.res.plan.local_index(self.res.rank)).to(self.dev) \
             if sampler == "device" else None
         self._d_q = self.res.quartet_buffer()
+        # the whole sample of a replicate as quartets on the destination rank's host (for the supertree step):
+        # unranked / sampled on the device into one of two buffers, copied out on the resolver's side stream
+        self.want_quartets = bool(quartets_to_host) and (dst is None or dst == self.res.rank)
+        self._d_full = [torch.empty((self.Q, 4), dtype=torch.int32, device=self.dev) for _ in range(2)] \
+            if self.want_quartets else None
+        self._d_ranks_full = torch.empty(self.Q, dtype=torch.int64, device=self.dev) \
+            if (self.want_quartets and sampler == "host") else None
 
     # -- the draws of one replicate, in the reference's order ---------------------------------------------
     def _draw(self):
@@ -89,6 +96,10 @@ class ReplicateRunner:
                 local[o:o + hi - lo] = idx[lo:hi]
                 o += hi - lo
             sample = local
+            if self.want_quartets:
+                full = pinned_empty(self.Q, np.int64)
+                full[...] = idx
+                sample = (local, full)
         else:
             sample = int(rng.integers(2**63))                                   # one seed for the device sampler
         return lidxs, s1, s2, sample, rng.bit_generator.state
@@ -109,8 +120,9 @@ class ReplicateRunner:
 
     # -- the loop -----------------------------------------------------------------------------------------
     def run(self, nreps: int, subsample_snps: bool = True, on_result: Optional[Callable] = None) -> dict:
-        """`nreps` bootstrap replicates.  `on_result(k, S, rstat, rscor, flags)` is called on the destination
-        rank as each replicate's rows arrive (host arrays owned by the callee).  Returns timing / flag stats."""
+        """`nreps` bootstrap replicates.  `on_result(k, S, rstat, rscor, flags)` -- with `quartets_to_host` also a
+        sixth argument `quartets` u32[Q,4], the replicate's sample in row order -- is called on the destination rank as
+        each replicate's rows arrive (host arrays owned by the callee).  Returns timing / flag stats."""
         torch, eng, res = self.torch, self.engine, self.res
         self._stop.clear()
         self._q = queue.Queue(maxsize=self.ahead)
@@ -127,7 +139,10 @@ class ReplicateRunner:
                 stats["flags"]["degenerate"] += int(((flags & 2) != 0).sum())
                 stats["flags"]["no_convergence"] += int(((flags & 8) != 0).sum())
                 if on_result is not None:
-                    on_result(k, S, rstat, rscor, flags)
+                    if self.want_quartets:
+                        on_result(k, S, rstat, rscor, flags, res.sets[b].pop("quartets"))
+                    else:
+                        on_result(k, S, rstat, rscor, flags)
 
         try:
             for k in range(nreps):
@@ -138,18 +153,34 @@ class ReplicateRunner:
                 self.rng_state_after.append(state)
                 S = eng.bootstrap(lidxs, s1, s2, stream=cur.cuda_stream)        # enqueued behind replicate k-1
                 stats["sites"].append(S)
-                if self.n_local:
-                    if self.sampler == "host":
-                        self._d_ranks.copy_(torch.from_numpy(sample), non_blocking=True)
-                        keep = sample                                           # alive until the copy has run
-                        eng.unrank_dev(self._d_ranks.data_ptr(), self.n_local, self._d_q.data_ptr(), cur.cuda_stream)
-                    else:
-                        keep = None
-                        eng.sample_quartets_dev(sample, self.Q, self._d_all.data_ptr(), 0, cur.cuda_stream)
-                        torch.index_select(self._d_all, 0, self._local_index, out=self._d_q)
                 b = k & 1
+                keep = None
+                if self.sampler == "host":
+                    local, full = sample if self.want_quartets else (sample, None)
+                    keep = (local, full)                                        # alive until the copies have run
+                    if self.n_local:
+                        self._d_ranks.copy_(torch.from_numpy(local), non_blocking=True)
+                        eng.unrank_dev(self._d_ranks.data_ptr(), self.n_local, self._d_q.data_ptr(), cur.cuda_stream)
+                    if self.want_quartets:
+                        self._d_ranks_full.copy_(torch.from_numpy(full), non_blocking=True)
+                        eng.unrank_dev(self._d_ranks_full.data_ptr(), self.Q, self._d_full[b].data_ptr(), cur.cuda_stream)
+                else:
+                    d_all = self._d_full[b] if self.want_quartets else self._d_all
+                    eng.sample_quartets_dev(sample, self.Q, d_all.data_ptr(), 0, cur.cuda_stream)
+                    if self.n_local:
+                        torch.index_select(d_all, 0, self._local_index, out=self._d_q)
+                q_host = None
+                if self.want_quartets:
+                    q_host = pinned_empty((self.Q, 4), np.uint32)
+                    if res.side is not None:
+                        res.side.wait_stream(cur)
+                        with torch.cuda.stream(res.side):
+                            torch.from_numpy(q_host.view(np.int32)).copy_(self._d_full[b], non_blocking=True)
+                    else:
+                        q_host[...] = self._d_full[b].cpu().numpy().view(np.uint32)
                 res.start(subsample_snps, b)
                 res.sets[b]["keep"] = keep
+                res.sets[b]["quartets"] = q_host
                 if pending is not None:
                     collect(*pending)
                 pending = (k, S, b)
@@ -164,3 +195,28 @@ class ReplicateRunner:
         self._stop.set()
         if self._thread is not None:
             self._thread.join()
+
+
+def bootstrap_trees(engine: QuartetEngine, seqarr: np.ndarray, spans: np.ndarray, nquartets: int, nboots: int, *,
+                    subsample_snps: bool = True, weights: int = 0, min_snps: int = 0, min_ratio: float = 1.0, seed=None,
+                    rng: Optional[np.random.Generator] = None, sampler: str = "host", group=None, workers: int = 4) -> list:
+    """The bootstrap part of run_inference.py:378-407 including the supertree step (:394): `nboots` replicates through
+    `ReplicateRunner`, each replicate's rows turned into a quartet supertree by the clean-room weighted Quartet MaxCut
+    (`qmc.infer_supertree_from_arrays`: same filters and weight strategies as :254-305) on a small thread pool while
+    the GPUs work on the next replicates.  Returns the newick strings in replicate order on the destination rank
+    (rank 0), an empty list elsewhere.  Tip labels are taxon numbers (`qmc.relabel_tree` turns them into names)."""
+    from concurrent.futures import ThreadPoolExecutor
+    from . import qmc
+    runner = ReplicateRunner(engine, seqarr, spans, nquartets, seed=seed, rng=rng, sampler=sampler, group=group,
+                             quartets_to_host=True)
+    ntaxa = int(seqarr.shape[0])
+    futures = {}
+    with ThreadPoolExecutor(max_workers=max(1, int(workers))) as pool:
+        def on_result(k, S, rstat, rscor, flags, quartets):
+            futures[k] = pool.submit(qmc.infer_supertree_from_arrays, quartets, rscor, rstat, ntaxa, weights, min_snps,
+                                     min_ratio, k)
+        try:
+            runner.run(nboots, subsample_snps, on_result=on_result)
+        finally:
+            runner.close()
+        return [futures[k].result() for k in sorted(futures)]

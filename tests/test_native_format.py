@@ -77,3 +77,10 @@ def test_write_qmc_from_arrays_is_a_seeded_permutation(tmp_path):
     assert a == (tmp_path / "b.txt").read_text()
     lines = [b.decode() for b in Q.qmc_lines(q, sc, st, 2)]
     assert n == len(lines) and sorted(a.splitlines()) == sorted(lines) and a.splitlines() != lines
+
+
+def test_tsv_pieces_concatenate_to_the_same_text():
+    q, sc, st = _rows(30_000, 8)
+    want = D.format_tsv_bytes(q, sc, st)
+    for threads, rows in ((4, 7_000), (8, 1 << 18), (1, 100)):
+        assert b"".join(D.format_tsv_pieces(q, sc, st, threads=threads, rows_per_piece=rows)) == want

@@ -382,6 +382,23 @@ def format_tsv_bytes(rqrts: np.ndarray, rscor: np.ndarray, rstat: np.ndarray) ->
     raise _lib.TetradHipError(rc, "tq_format_tsv: buffer sizing failed")
 
 
+def format_tsv_pieces(rqrts: np.ndarray, rscor: np.ndarray, rstat: np.ndarray, threads: int = 8, rows_per_piece: int = 1 << 18):
+    """The same text as `format_tsv_bytes`, as a list of consecutive byte pieces formatted on a thread pool (the native
+    formatter runs without the GIL): 5e6 rows take ~0.6 s on one core -- longer than the GPUs need to resolve them."""
+    from concurrent.futures import ThreadPoolExecutor
+    q = np.ascontiguousarray(rqrts, dtype=np.uint32).reshape(-1, 4)
+    st = np.ascontiguousarray(rstat, dtype=np.uint32).reshape(-1, 2)
+    sc = np.ascontiguousarray(rscor, dtype=np.float64).reshape(-1, 3)
+    n = q.shape[0]
+    if st.shape[0] != n or sc.shape[0] != n:
+        raise ValueError("rqrts, rscor and rstat must have the same number of rows")
+    if n <= rows_per_piece or threads <= 1:
+        return [format_tsv_bytes(q, sc, st)]
+    cuts = list(range(0, n, rows_per_piece)) + [n]
+    with ThreadPoolExecutor(max_workers=int(threads)) as pool:
+        return list(pool.map(lambda ab: format_tsv_bytes(q[ab[0]:ab[1]], sc[ab[0]:ab[1]], st[ab[0]:ab[1]]), zip(cuts[:-1], cuts[1:])))
+
+
 def format_tsv(rqrts: np.ndarray, rscor: np.ndarray, rstat: np.ndarray) -> str:
     """Same text as the reference's
     ``pd.concat([DataFrame(rqrts), DataFrame(rscor), DataFrame(rstat)], axis=1)
@@ -417,7 +434,8 @@ def distributor(database_file: Path, qrts_file: Path, nsamples: int, qiter: Iter
                                                  compute=compute, dst=0)
         if rank == 0:
             with open(qrts_file, "ab") as out:                     # :240-244
-                out.write(format_tsv_bytes(rqrts, rscor, rstat))
+                for piece in format_tsv_pieces(rqrts, rscor, rstat):
+                    out.write(piece)
 
     parts, nrows = [], 0
     for chunk in qiter:                                            # :216-223

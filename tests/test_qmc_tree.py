@@ -211,3 +211,19 @@ def test_qmc_splits_equal_the_parsed_lines(weights, min_snps, min_ratio):
     sp2, w2 = qmc.parse_qmc_lines(qmc_format.qmc_lines(q, sc, st, weights, min_snps, min_ratio))
     np.testing.assert_array_equal(sp, sp2)
     np.testing.assert_array_equal(w, w2)
+
+
+def test_infer_supertree_file_pipeline(tmp_path):
+    """quartets TSV (as the distributor writes it) -> wQMC input file -> tree file -> named newick"""
+    from conftest import load_golden
+    from tetrad_amd import distributor
+    g = load_golden("c1_T16_S5000")
+    tsv = tmp_path / "x.quartets_0.tsv"
+    tsv.write_bytes(distributor.format_tsv_bytes(g["quartets"], g["sub_rscor"], g["sub_rstat"]))
+    names = {i: f"sample_{i}" for i in range(16)}
+    nwk = qmc.infer_supertree(tsv, tmp_path / "qmc_in.txt", tmp_path / "qmc_out.txt", 16, weights=1, samples=names)
+    assert nwk.count("sample_") == 16 and nwk.endswith(";")
+    numeric = (tmp_path / "qmc_out.txt").read_text().strip()
+    children, root = synth.random_tree_children(16, np.random.default_rng(synth.CONFIG_SEEDS["c1"]))
+    assert _bipartitions_from_newick(numeric, 16) == _bipartitions_from_children(children, root, 16)
+    assert len((tmp_path / "qmc_in.txt").read_text().splitlines()) == 1820

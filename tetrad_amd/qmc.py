@@ -107,3 +107,15 @@ def relabel_tree(newick: str, samples) -> str:
         return m.group(1) + name
 
     return re.sub(r"([(,])(\d+)(?=[,):])", sub, newick)
+
+
+def infer_supertree(qrts_file: Path, qmc_in_file: Path, qmc_out_file: Path, ntaxa: int, weights: int = 0, min_snps: int = 0,
+                    min_ratio: float = 1.0, samples=None, seed: int = 0) -> str:
+    """run_inference.py:330-357 on explicit paths instead of a Project: the quartets TSV -> shuffled wQMC input file
+    (`qmc_format.write_qmc_format`) -> tree file (`run_qmc`) -> newick with sample names when `samples` is given
+    (`relabel_tree`), numeric tips otherwise."""
+    from .qmc_format import write_qmc_format
+    write_qmc_format(qrts_file, qmc_in_file, weights, min_snps, min_ratio, seed=seed)      # :347
+    run_qmc(qmc_in_file, qmc_out_file, bool(weights), ntaxa=ntaxa, seed=seed)              # :350
+    nwk = Path(qmc_out_file).read_text().strip()
+    return relabel_tree(nwk, samples) if samples is not None else nwk                      # :353

@@ -104,7 +104,8 @@ def cpu_baseline(tmparr, tmpmap, quartets, sub, gpu_rstat, gpu_rscor, budget_s=1
     wall2 = min(time.perf_counter() - t0, max(r[0] for r in res2))
     rstat2 = np.concatenate([r[1] for r in res2])
     parity["tuned_cpu_variant_topology_equal"] = bool(np.array_equal(rstat2[:, 0], gpu_rstat[:n2, 0]))
-    return dict(value=n / wall, unit="quartets/s", cores=cores, cpu_model=model, kind="port",
+    return dict(value=n / wall, unit="quartets/s", cores=cores, host_cores_total=os.cpu_count(),
+                host_cores_available_to_this_process=len(os.sched_getaffinity(0)), cpu_model=model, kind="port",
                 tuned_variant=dict(value=n2 / wall2, unit="quartets/s", cores=cores,
                                    what=f"first {n2} quartets, compiled count loop + one batched values-only "
                                         f"numpy.linalg.svd per chunk (no interpreter in the per-quartet loop "
@@ -199,14 +200,16 @@ def hbm_copy_rate(torch, dev):
     return 5 * 2 * (1 << 30) / (e0.elapsed_time(e1) / 1e3) / 1e9
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--config", default=None, choices=["c2", "c3", "c4", "c5"],
-                    help="default: c3 on one GPU, c4 (strong scaling) on several")
-    ap.add_argument("--weak", action="store_true", help="N > 1: every rank its own 1e6 quartets of the c3 matrix")
+                    help="default: c3 (one GPU: 1e6 quartets; N GPUs: N x 1e6, weak scaling, then a c4 strong-scaling leg)")
+    ap.add_argument("--weak", action="store_true", help="N > 1: every rank its own 1e6 quartets of the c3 matrix (the default)")
+    ap.add_argument("--no-c4-leg", action="store_true",
+                    help="N > 1 default run: skip the secondary c4 strong-scaling leg (BASELINE.json configs[3])")
     ap.add_argument("--quartets", type=int, default=0, help="quartets in the batch (0 = config default)")
     ap.add_argument("--full", action="store_true", help="subsample_snps=False")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
@@ -215,37 +218,135 @@ def main():
     ap.add_argument("--pieces", type=int, default=0, help="N > 1: result pieces per batch (0 = automatic)")
     ap.add_argument("--sharded", action="store_true",
                     help="take the N > 1 code path (process group, all-gather per piece, regrouping, verification) "
-                         "even with one rank: a one-GPU rehearsal of the RCCL path when launched through torch.distributed.run")
+                         "even with one rank: a one-GPU rehearsal of the RCCL path")
     ap.add_argument("--sampler", default="host", choices=["host", "device"],
                     help="c5: quartet sample drawn on the project Generator (reference stream) or on the device")
     ap.add_argument("--svd-chunk", type=int, default=0)
     ap.add_argument("--order", type=int, default=-1, help="0 = natural quartet order, 1 = sorted (default)")
     ap.add_argument("--phases", type=int, default=0, help="diagnostic: 1 scan only, 2 SVD only (invalid as a result)")
-    args = ap.parse_args()
+    ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE", help="engine option (tq_set_option), repeatable")
+    ap.add_argument("--launch-probe", action="store_true",
+                    help="self-test of the rank launcher and the rendezvous only (no GPU work, NOT a result): every rank "
+                         "joins a gloo group, rank 0 prints what the group saw")
+    return ap.parse_args(argv)
+
+
+def _free_port() -> int:
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(args, argv) -> int:
+    """`python bench.py --gpus N` without a launcher environment: start the N ranks ourselves.
+
+    This process has not touched the GPU (no HIP call, no torch.cuda call other than device_count) and never
+    will: it starts N fresh children -- one process per GPU, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set as
+    torch.distributed.run would -- relays rank 0's JSON line, and exits with the worst child status.  If a rank
+    dies the others are ended by their exact PIDs (they would wait in a collective forever)."""
+    n = args.gpus
+    if args.backend == "nccl":
+        import torch
+        ndev = torch.cuda.device_count()            # does not initialise the GPU on this image
+        if ndev < n:
+            sys.stderr.write(f"bench.py: --gpus {n} with backend nccl needs {n} visible GPUs, found {ndev} "
+                             f"(use --backend gloo to rehearse the {n}-rank control flow on fewer GPUs)\n")
+            return 2
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+               TQ_BENCH_SELF_LAUNCHED="1")
+    procs = []
+    for r in range(n):
+        e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, str(Path(__file__).resolve())] + list(argv), env=e,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, stderr=sys.stderr))
+    import threading
+    out0 = []
+    t = threading.Thread(target=lambda: out0.append(procs[0].stdout.read()), daemon=True)
+    t.start()
+    worst, alive = 0, set(range(n))
+    while alive:
+        for r in sorted(alive):
+            rc = procs[r].poll()
+            if rc is None:
+                continue
+            alive.discard(r)
+            if rc != 0 and worst == 0:
+                worst = rc if rc > 0 else 1
+                sys.stderr.write(f"bench.py: rank {r} exited with status {rc}; ending the other ranks\n")
+                for o in alive:
+                    procs[o].terminate()            # exact PIDs of our own children
+        time.sleep(0.05)
+    t.join(timeout=10)
+    if out0:
+        # the contract is ONE JSON line on stdout: anything else rank 0 wrote there (gloo's C++ side prints its
+        # connection report to stdout) goes to stderr
+        for ln in out0[0].decode(errors="replace").splitlines():
+            (sys.stdout if ln.lstrip().startswith("{") else sys.stderr).write(ln + "\n")
+        sys.stdout.flush()
+    return worst
+
+
+def launch_probe(args):
+    """--launch-probe: what a child rank does instead of the benchmark (tests/test_bench_launcher.py)."""
+    import torch
+    import torch.distributed as dist
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    if os.environ.get("TQ_BENCH_PROBE_FAIL_RANK") == str(rank):
+        raise SystemExit(7)
+    if world > 1:
+        dist.init_process_group("gloo")
+        t = torch.tensor([rank + 1], dtype=torch.int64)
+        dist.all_reduce(t)
+        seen, total = dist.get_world_size(), int(t.item())
+        dist.barrier()
+        dist.destroy_process_group()
+    else:
+        seen, total = 1, 1
+    if rank == 0:
+        print(json.dumps({"probe": True, "n_gpus": seen, "gpus_arg": args.gpus, "rank_sum": total,
+                          "local_ranks_distinct": True, "self_launched": bool(os.environ.get("TQ_BENCH_SELF_LAUNCHED")),
+                          "master_addr": os.environ.get("MASTER_ADDR")}), flush=True)
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    args = parse_args(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
+        raise SystemExit(launch_ranks(args, argv))
+
+    if args.launch_probe:
+        return launch_probe(args)
 
     import torch
     from tetrad_amd import synth
     from tetrad_amd.engine import QuartetEngine, pinned_empty
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
+    env_world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if env_world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={env_world}")
     ndev = torch.cuda.device_count()
     dev_index = local_rank if args.backend == "nccl" else local_rank % max(1, ndev)
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     dist = None
-    multi = world > 1 or (args.sharded and "RANK" in os.environ)
+    multi = env_world > 1 or (args.sharded and "RANK" in os.environ)
+    world, rank = 1, 0
     if multi:
         import torch.distributed as dist
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group("gloo")
+        world, rank = dist.get_world_size(), dist.get_rank()      # what the collective library actually sees
+        if world != args.gpus:
+            raise SystemExit(f"--gpus {args.gpus} but the process group has {world} ranks")
 
-    cfg = args.config or ("c3" if not multi else ("c3" if args.weak else "c4"))
+    cfg = args.config or "c3"
+    weak = multi and cfg == "c3"                  # N > 1 on the c3 shape: per-GPU work fixed (the N = 1 workload per rank)
     if args.weak and cfg != "c3":
         raise SystemExit("--weak is the c3 shape")
     sub = not args.full
@@ -256,32 +357,133 @@ def main():
         eng.set_option("order", args.order)
     if args.svd_chunk:
         eng.set_option("svd_chunk", args.svd_chunk)
+    for kv in args.opt:
+        k, v = kv.split("=", 1)
+        eng.set_option(k, int(v))
 
     if cfg == "c5":
         return bench_c5(args, eng, torch, dist, dev, world, rank)
-
-    T, S, qdef = synth.CONFIGS[cfg]
-    tmparr, tmpmap = synth.simulate_tmparr(T, S, synth.CONFIG_SEEDS[cfg])
-    eng.set_data(tmparr, tmpmap)
-    lexi = qdef is None and not args.quartets
-    if lexi:
-        Q = int(synth.comb(T, 4))
-        ranks_all = np.arange(Q, dtype=np.int64)
-    else:
-        Q = args.quartets or qdef
-        if args.weak:
-            Q *= world
-        # ONE seeded sample for the whole job, identical on every rank (combinations.py:109-114)
-        ranks_all = np.random.default_rng(synth.CONFIG_SEEDS[cfg] + 1000).choice(
-            synth.comb(T, 4), size=Q, replace=False).astype(np.int64)
-    stream = torch.cuda.current_stream().cuda_stream
 
     def barrier():
         if multi:
             dist.barrier()
         torch.cuda.synchronize()
 
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def make_workload(cfg, weak):
+        T, S, qdef = synth.CONFIGS[cfg]
+        tmparr, tmpmap = synth.simulate_tmparr(T, S, synth.CONFIG_SEEDS[cfg])
+        eng.set_data(tmparr, tmpmap)
+        lexi = qdef is None and not args.quartets
+        if lexi:
+            Q = int(synth.comb(T, 4))
+            ranks_all = np.arange(Q, dtype=np.int64)
+        else:
+            Q = args.quartets or qdef
+            if weak:
+                Q *= world
+            # ONE seeded sample for the whole job, identical on every rank (combinations.py:109-114)
+            ranks_all = np.random.default_rng(synth.CONFIG_SEEDS[cfg] + 1000).choice(
+                synth.comb(T, 4), size=Q, replace=False).astype(np.int64)
+        return dict(cfg=cfg, T=T, S=S, Q=Q, lexi=lexi, weak=weak, tmparr=tmparr, tmpmap=tmpmap, ranks_all=ranks_all)
+
+    def one_gpu_pass(ranks, steps, warm=1):
+        """tq_resolve_to_host on THIS rank's GPU alone over the quartets with lexicographic ranks `ranks`:
+        returns (quartets/s, (rstat, rscor, flags), device quartets)."""
+        n = len(ranks)
+        d_r = torch.from_numpy(np.ascontiguousarray(ranks)).to(dev)
+        d_q = torch.empty((n, 4), dtype=torch.int32, device=dev)
+        eng.unrank_dev(d_r.data_ptr(), n, d_q.data_ptr(), stream)
+        torch.cuda.synchronize()
+        out = (pinned_empty((n, 2), np.uint32), pinned_empty((n, 3), np.float64), pinned_empty(n, np.uint8))
+        for _ in range(warm):
+            eng.resolve_to_host(d_q.data_ptr(), n, sub, out=out)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            eng.resolve_to_host(d_q.data_ptr(), n, sub, out=out)
+        torch.cuda.synchronize()
+        return n * steps / (time.perf_counter() - t0), out, d_q
+
+    def run_sharded(wl, steps, warmup, timing=True):
+        """The N-rank path over workload `wl`: returns a dict with the max-over-ranks elapsed time of `steps`
+        steps, the gathered rows (rank 0), the verification of the gather and the in-run one-GPU figure."""
+        from tetrad_amd.distributor import ShardedResolver
+        Q = wl["Q"]
+        res = ShardedResolver(Q, engine=eng, device=dev_index, dst=0, pieces=args.pieces or None,
+                              collective_always=True)
+        res.set_ranks(wl["ranks_all"])
+        torch.cuda.synchronize()
+        last = [None]
+
+        def step():
+            last[0] = None                  # hand the previous rows back to the pinned pool before new ones are taken
+            res.start(sub)
+            last[0] = res.finish()
+
+        for _ in range(warmup):
+            step()
+        barrier()
+        eng.timing_enable(timing)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        barrier()
+        elapsed = time.perf_counter() - t0
+        kms, launches = eng.timing_read_kernels() if timing else ({}, 0)
+        eng.timing_enable(False)
+        gdev = dev if args.backend == "nccl" else torch.device("cpu")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=gdev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        rstat, rscor, flags = last[0]
+        # the gathered rows on rank 0 against what every rank computed itself: a checksum over each rank's
+        # own rows and 64 sampled rows per rank, compared bit for bit
+        P = res.plan
+        own = res.device_rows()
+        idx = torch.from_numpy(P.local_index(rank)).to(own[0].device)
+        mine = [x.index_select(0, idx) for x in own] if len(idx) else None
+        pick = np.random.default_rng(rank).integers(0, max(1, len(idx)), size=min(64, len(idx)))
+        rec = dict(rank=rank, n=int(len(idx)),
+                   nsnps_sum=int(mine[0][:, 1].to(torch.int64).sum().item()) if mine else 0,
+                   score_bits_xor=int(np.bitwise_xor.reduce(mine[1].cpu().numpy().view(np.int64).ravel())) if mine else 0,
+                   rows=[(int(P.local_index(rank)[i]), mine[0][i].tolist(), mine[1][i].cpu().numpy().view(np.int64).tolist())
+                         for i in pick] if mine else [])
+        recs = [None] * world
+        dist.all_gather_object(recs, rec)
+        out = dict(elapsed=elapsed, kms=kms, launches=launches, n_local=res.n_local, rows=(rstat, rscor, flags))
+        if rank == 0:
+            ok = True
+            for r in recs:
+                gi = P.local_index(r["rank"])
+                ok &= int(rstat[gi, 1].astype(np.int64).sum()) == r["nsnps_sum"]
+                ok &= int(np.bitwise_xor.reduce(rscor[gi].view(np.int64).ravel())) == r["score_bits_xor"] if len(gi) else True
+                for g, rs, sc in r["rows"]:
+                    ok &= rstat[g].astype(np.int64).tolist() == [x & 0xFFFFFFFF for x in rs]
+                    ok &= rscor[g].view(np.int64).tolist() == sc
+            out.update(gather_verified=bool(ok), gather_pieces=P.npieces, rows_per_piece_per_rank=P.part)
+        # the like-for-like one-GPU figure, MEASURED IN THIS RUN: rank 0 alone resolves the same quartets one GPU
+        # would own in the single-GPU form of this workload (strong: the whole batch; weak: one rank's 1/N share)
+        # through tq_resolve_to_host while the other ranks wait at the barrier
+        del res, own, mine, idx
+        torch.cuda.empty_cache()
+        barrier()
+        if rank == 0:
+            ranks1 = wl["ranks_all"] if not wl["weak"] else wl["ranks_all"][:Q // world]
+            v1, out1, _ = one_gpu_pass(ranks1, min(3, steps))
+            out["one_gpu_same_run_value"] = v1
+            out["one_gpu_same_run_quartets"] = int(len(ranks1))
+            n1 = len(ranks1)
+            out["one_gpu_rows_equal_gathered_rows"] = bool(np.array_equal(out1[0], rstat[:n1]) and
+                                                           np.array_equal(out1[1], rscor[:n1]))
+        barrier()
+        return out
+
     extra = {}
+    wl = make_workload(cfg, weak)
+    T, S, Q, lexi = wl["T"], wl["S"], wl["Q"], wl["lexi"]
+    tmparr, tmpmap, ranks_all = wl["tmparr"], wl["tmpmap"], wl["ranks_all"]
     if not multi:
         d_r = torch.from_numpy(ranks_all).to(dev)
         d_q = torch.empty((Q, 4), dtype=torch.int32, device=dev)
@@ -292,54 +494,30 @@ def main():
         def step():
             eng.resolve_to_host(d_q.data_ptr(), Q, sub, out=out)
 
-        def results():
-            return out
-    else:
-        from tetrad_amd.distributor import ShardedResolver
-        res = ShardedResolver(Q, engine=eng, device=dev_index, dst=0, pieces=args.pieces or None,
-                              collective_always=True)
-        res.set_ranks(ranks_all)
-        torch.cuda.synchronize()
-        last = [None]
-
-        def step():
-            last[0] = None                  # hand the previous rows back to the pinned pool before new ones are taken
-            res.start(sub)
-            last[0] = res.finish()
-
-        def results():
-            return last[0]
-
-    for _ in range(args.warmup):
+        for _ in range(args.warmup):
+            step()
+        barrier()
+        eng.timing_enable(True)
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        barrier()
+        elapsed = time.perf_counter() - t0
+        kms, launches = eng.timing_read_kernels()
+        # per-kernel durations of the singular-value stage: in the timed region two chunks run concurrently on
+        # two streams (one chunk's tail is filled by the next), so their event spans overlap; three more steps
+        # with the chunks serialised on one stream give each kernel's own duration for roofline.kernels[]
+        eng.set_option("svd_streams", 1)
         step()
-    barrier()
-    eng.timing_enable(True)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    kms, launches = eng.timing_read_kernels()
-    # per-kernel durations of the singular-value stage: in the timed region two chunks run concurrently on
-    # two streams (one chunk's tail is filled by the next), so their event spans overlap; three more steps
-    # with the chunks serialised on one stream give each kernel's own duration for roofline.kernels[]
-    eng.set_option("svd_streams", 1)
-    step()
-    eng.timing_read_kernels()
-    for _ in range(3):
-        step()
-    kms_serial, launches_serial = eng.timing_read_kernels()
-    eng.set_option("svd_streams", 0)
-    eng.timing_enable(False)
-    if multi:
-        gdev = dev if args.backend == "nccl" else torch.device("cpu")
-        t = torch.tensor([elapsed], dtype=torch.float64, device=gdev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    step()                                  # results of the default configuration
-
-    rstat, rscor, flags = results()
-    if not multi:
+        eng.timing_read_kernels()
+        for _ in range(3):
+            step()
+        kms_serial, launches_serial = eng.timing_read_kernels()
+        eng.set_option("svd_streams", 0)
+        eng.timing_enable(False)
+        step()                                  # results of the default configuration
+        rstat, rscor, flags = out
+        q_rank = Q
         # device-resident rate (no result D2H) and the PCIe-inclusive rate of the host-buffer API (quartets
         # H2D from a page-locked array + results D2H per call); reported beside `value`, never as `value`
         quartets_h = pinned_empty((Q, 4), np.uint32)
@@ -374,43 +552,36 @@ def main():
         for _ in range(3):
             pageable_call()
         extra["pcie_inclusive_value_pageable_arrays"] = 3 * Q / (time.perf_counter() - t1)
+        extra["pageable_api_equals_timed_path"] = bool(np.array_equal(out_pg[0], rstat) and np.array_equal(out_pg[1], rscor))
     else:
-        # the gathered rows on rank 0 against what every rank computed itself: a checksum over each rank's
-        # own rows and 64 sampled rows per rank, compared bit for bit
-        P = res.plan
-        own = res.device_rows()
-        idx = torch.from_numpy(P.local_index(rank)).to(own[0].device)
-        mine = [x.index_select(0, idx) for x in own] if len(idx) else None
-        pick = np.random.default_rng(rank).integers(0, max(1, len(idx)), size=min(64, len(idx)))
-        rec = dict(rank=rank, n=int(len(idx)),
-                   nsnps_sum=int(mine[0][:, 1].to(torch.int64).sum().item()) if mine else 0,
-                   score_bits_xor=int(np.bitwise_xor.reduce(mine[1].cpu().numpy().view(np.int64).ravel())) if mine else 0,
-                   rows=[(int(P.local_index(rank)[i]), mine[0][i].tolist(), mine[1][i].cpu().numpy().view(np.int64).tolist())
-                         for i in pick] if mine else [])
-        recs = [None] * world
-        dist.all_gather_object(recs, rec)
+        r = run_sharded(wl, args.steps, args.warmup)
+        elapsed, kms, launches, q_rank = r["elapsed"], r["kms"], r["launches"], r["n_local"]
+        kms_serial, launches_serial = kms, launches
+        rstat, rscor, flags = r["rows"]
         if rank == 0:
-            ok = True
-            for r in recs:
-                gi = P.local_index(r["rank"])
-                ok &= int(rstat[gi, 1].astype(np.int64).sum()) == r["nsnps_sum"]
-                ok &= int(np.bitwise_xor.reduce(rscor[gi].view(np.int64).ravel())) == r["score_bits_xor"] if len(gi) else True
-                for g, rs, sc in r["rows"]:
-                    ok &= rstat[g].astype(np.int64).tolist() == [x & 0xFFFFFFFF for x in rs]
-                    ok &= rscor[g].view(np.int64).tolist() == sc
-            extra["gather_verified"] = bool(ok)
-            extra["gather_pieces"] = P.npieces
-            extra["rows_per_piece_per_rank"] = P.part
-            # the SAME workload on one GPU, for a like-for-like scaling figure (the default N = 1 run is c3, a
-            # lighter shape): quoted from the committed one-GPU line of this config, not measured in this run
-            ref = REPO / "profiles" / "r02_pipeline" / f"bench_{cfg}_n1.json"
-            if ref.exists() and not args.quartets and not args.weak:
-                try:
-                    r1 = json.loads(ref.read_text())
-                    extra["same_workload_on_one_gpu"] = dict(value=r1["value"], commit=r1.get("commit"),
-                                                             source=f"profiles/r02_pipeline/{ref.name} (not measured in this run)")
-                except Exception:
-                    pass
+            value = Q * args.steps / elapsed
+            for k in ("gather_verified", "gather_pieces", "rows_per_piece_per_rank", "one_gpu_same_run_value",
+                      "one_gpu_same_run_quartets", "one_gpu_rows_equal_gathered_rows"):
+                extra[k] = r[k]
+            extra["speedup"] = value / r["one_gpu_same_run_value"]
+            extra["speedup_note"] = ("value / one_gpu_same_run_value: rank 0 alone, same run, "
+                                     + ("one rank's share of the batch (weak scaling: ideal = n_gpus)" if weak
+                                        else "the whole batch (strong scaling: ideal = n_gpus)"))
+        # secondary leg of the default N > 1 run: BASELINE.json configs[3] (c4, ONE 5e6-quartet batch cut over the
+        # ranks: strong scaling) with its own in-run one-GPU figure
+        if cfg == "c3" and not args.config and not args.no_c4_leg and not args.quartets:
+            wl4 = make_workload("c4", False)
+            r4 = run_sharded(wl4, min(args.steps, 3), 1, timing=False)
+            if rank == 0:
+                v4 = wl4["Q"] * min(args.steps, 3) / r4["elapsed"]
+                extra["c4_strong_leg"] = dict(
+                    workload=f"c4: {wl4['T']} taxa x {wl4['S']} SNPs, ONE batch of {wl4['Q']} random quartets cut over "
+                             f"{world} GPUs (strong scaling), subsample_snps={sub}, rows to rank 0's host",
+                    value=v4, unit="quartets/s", steps=min(args.steps, 3), scaling="strong",
+                    ms_per_step=r4["elapsed"] / min(args.steps, 3) * 1e3,
+                    one_gpu_same_run_value=r4["one_gpu_same_run_value"], speedup=v4 / r4["one_gpu_same_run_value"],
+                    gather_verified=r4["gather_verified"], gather_pieces=r4["gather_pieces"],
+                    one_gpu_rows_equal_gathered_rows=r4["one_gpu_rows_equal_gathered_rows"])
 
     hbm_copy = hbm_copy_rate(torch, dev) if rank == 0 else None
 
@@ -418,8 +589,7 @@ def main():
         ms_per_step = elapsed / args.steps * 1e3
         value = Q * args.steps / elapsed
         A = 4 * S + 48                                   # algorithmic bytes per quartet
-        q_rank = res.n_local if multi else Q               # quartets one launch of the scan kernel covers here
-        bytes_per_launch = q_rank * A + 4 * S
+        bytes_per_launch = q_rank * A + 4 * S              # q_rank = quartets one launch of the scan kernel covers here
         per_pass = {k: v / max(1, launches) for k, v in kms.items()}
         dominant_ms = per_pass["scan"]
         achieved = bytes_per_launch / (dominant_ms / 1e3) / 1e9
@@ -432,33 +602,24 @@ def main():
                            f"(commit {tj.get('commit', 'unknown')}); not re-measured in this run")
         what = ("lexicographic (all)" if lexi else "random")
         workload = (f"{cfg}: {T} taxa x {S} SNPs, {Q} {what} quartets"
-                    + (f" in one batch cut over {world} GPUs (strong scaling)" if multi and not args.weak else "")
-                    + (f" = {Q // world} per GPU (weak scaling)" if args.weak else "")
+                    + (f" in one batch cut over {world} GPUs (strong scaling)" if multi and not weak else "")
+                    + (f" = {Q // world} per GPU (weak scaling: the N = 1 workload on every GPU)" if weak else "")
                     + f", subsample_snps={sub}, results delivered to host arrays inside the step")
+        kernels = kernel_rooflines(kms_serial, launches_serial, q_rank, S, sub, cfg)
         line = {
             "metric": "resolved quartets/sec (whole node)", "value": value, "unit": "quartets/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
-            "higher_is_better": True, "scaling": "weak" if (args.weak or not multi) else "strong",
+            "higher_is_better": True, "scaling": "strong" if (multi and not weak) else "weak",
             "vs_baseline": None,
             "dtype": "u8 scan / u32 counts / f64 SVD", "data": "synthetic",
             "config": {"workload": workload, "quartets": Q, "taxa": T, "snps": S, "subsample_snps": sub,
                        "parallelism": (f"quartet-sharded x{world}, one all-gather per result piece, rows to rank 0's host"
-                                       if multi else "one GPU, result D2H overlapped inside tq_resolve_to_host")},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS,
-                         "note": ("algorithmic bytes (SURVEY 8d: 4*S+48 per quartet) over the dominant kernel's time; the "
-                                  "genotype matrix is L2 / Infinity-Cache resident, so this exceeds the HBM peak and is NOT an "
-                                  "efficiency figure -- see kernels[].frac for each kernel against the roof that binds it"),
-                         "kernel": "tq_scan_wg_kernel", "kernel_ms": dominant_ms,
-                         "algorithmic_bytes_per_launch": bytes_per_launch,
-                         "traffic": traffic, "traffic_source": traffic_src,
-                         "hbm_copy_measured_GBs": hbm_copy,
-                         "scan_stage_ms_per_step": per_pass["order"] + per_pass["scan"],
-                         "kernels_note": ("ms of each kernel per step from 3 extra steps of this run with the singular-value "
-                                          "chunks serialised on one stream; in the timed region two chunks overlap on two "
-                                          "streams (sum of their event spans per step: "
-                                          f"{per_pass['bidiag'] + per_pass['bdsqr'] + per_pass['score']:.3f} ms)"),
-                         "kernels": kernel_rooflines(kms_serial, launches_serial, q_rank, S, sub, cfg)},
+                                       if multi else "one GPU, result D2H overlapped inside tq_resolve_to_host"),
+                       "launcher": ("bench.py started the ranks itself" if os.environ.get("TQ_BENCH_SELF_LAUNCHED")
+                                    else ("torch.distributed.run / external" if multi else "none (one process)")),
+                       "backend": (args.backend if multi else None)},
+            "roofline": roofline_block(achieved, dominant_ms, bytes_per_launch, traffic, traffic_src, hbm_copy, per_pass,
+                                       kernels, multi),
             "flags": {"zero_data": int((flags & 1).sum()), "degenerate": int(((flags & 2) > 0).sum()),
                       "no_convergence": int(((flags & 8) > 0).sum())},
             "commit": git_head(),
@@ -476,6 +637,46 @@ def main():
     if multi:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def roofline_block(achieved, dominant_ms, bytes_per_launch, traffic, traffic_src, hbm_copy, per_pass, kernels, multi):
+    """The contract's roofline object (algorithmic bytes over the dominant kernel's HIP-event time against the HBM
+    peak) plus SCALAR efficiency keys a flat parser keeps: which unit actually binds the dominant kernel and how
+    busy it is (committed rocprofv3 --pmc summary, quoted with its commit), the useful-f64-flop fraction of the
+    singular-value kernels, and counter traffic over algorithmic bytes."""
+    scan = next((k for k in kernels if k["name"].startswith("tq_scan")), None)
+    pmc = (scan or {}).get("pmc") or {}
+    valu, lds = pmc.get("valu_busy"), pmc.get("lds_busy")
+    binding, binding_frac = None, None
+    if valu is not None and lds is not None:
+        binding = "valu+lds" if abs(valu - lds) < 0.1 else ("valu" if valu > lds else "lds")
+        binding_frac = max(valu, lds)
+    svd = [k for k in kernels if k["name"] in ("tq_bidiag_kernel", "tq_bdsqr_kernel")]
+    svd_frac = None
+    if svd and all(k.get("ms") for k in svd):
+        flop = sum(k["achieved"] * 1e12 * k["ms"] / 1e3 for k in svd)
+        svd_frac = flop / (sum(k["ms"] for k in svd) / 1e3) / 1e12 / F64_VECTOR_PEAK_TFLOPS
+    out = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+           "frac": achieved / HBM_PEAK_GBS,
+           "note": ("algorithmic bytes (SURVEY 8d: 4*S+48 per quartet) over the dominant kernel's time; the "
+                    "genotype matrix is L2 / Infinity-Cache resident, so this exceeds the HBM peak and is NOT an "
+                    "efficiency figure -- binding / binding_frac / svd_f64_frac / kernels[].frac are"),
+           "kernel": "tq_scan_wg_kernel", "kernel_ms": dominant_ms,
+           "algorithmic_bytes_per_launch": bytes_per_launch,
+           "traffic": traffic, "traffic_source": traffic_src,
+           "traffic_over_algorithmic": (traffic / bytes_per_launch if traffic else None),
+           "binding": binding, "binding_frac": binding_frac,
+           "binding_source": (pmc.get("source"), pmc.get("commit")) if pmc else None,
+           "scan_l2_to_cu_frac": (scan or {}).get("frac"),
+           "svd_f64_frac": svd_frac,
+           "hbm_copy_measured_GBs": hbm_copy,
+           "scan_stage_ms_per_step": per_pass.get("order", 0) + per_pass.get("scan", 0),
+           "svd_stage_ms_per_step_serialised": sum(k["ms"] for k in kernels if k["name"].startswith(("tq_bidiag", "tq_bdsqr", "tq_score"))),
+           "kernels_note": ("ms of each kernel per step" + ("" if multi else " from 3 extra steps of this run with the singular-value "
+                            "chunks serialised on one stream; in the timed region two chunks overlap on two streams (sum of "
+                            f"their event spans per step: {per_pass.get('bidiag', 0) + per_pass.get('bdsqr', 0) + per_pass.get('score', 0):.3f} ms)")),
+           "kernels": kernels}
+    return out
 
 
 def bench_c5(args, eng, torch, dist, dev, world, rank):

@@ -103,3 +103,23 @@ def test_two_ranks_with_the_engine_equal_one_engine(tmp_path):
             np.testing.assert_array_equal(z[f"rstat{k}"], one[k][0])
             np.testing.assert_array_equal(z[f"rscor{k}"], one[k][1])
             np.testing.assert_array_equal(z[f"flags{k}"], one[k][2])
+
+
+@pytest.mark.gpu
+def test_bare_bench_command_runs_two_ranks():
+    """The driver's form of the command -- `python bench.py --gpus 2`, no launcher environment -- must start
+    two ranks itself and report what the process group saw (gloo: both ranks share the one GPU of this box)."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, str(REPO / "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "2",
+                        "--warmup", "1", "--quartets", "40000"], capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak"
+    assert d["config"]["quartets"] == 80000                      # weak: every rank its own 40 000
+    assert d["gather_verified"] is True
+    assert d["one_gpu_rows_equal_gathered_rows"] is True
+    assert d["one_gpu_same_run_value"] > 0 and d["speedup"] > 0
+    assert d["config"]["launcher"].startswith("bench.py started")

@@ -223,6 +223,21 @@ def test_device_pointer_api_and_unranking(engine):
     np.testing.assert_array_equal(rstat2.cpu().numpy().astype(np.uint32), g["sub_rstat"][ranks])
 
 
+@pytest.mark.parametrize("T", [16, 64, 128, 256])
+def test_device_unranking_equals_reference_fixture(engine, T):
+    """tq_unrank_dev (tq_unrank_kernel) against the reference's own `_index_to_combination` outputs
+    (combinations.py:94-106; tests/golden/host_f2f3.npz made by make_golden_host.py)."""
+    import torch
+    g = load_golden("host_f2f3")
+    ranks, want = g[f"unrank_T{T}_ranks"], g[f"unrank_T{T}_quartets"]
+    engine.set_data(np.zeros((T, 64), np.uint8), np.zeros((64, 2), np.uint32))      # the kernel takes T from the data
+    d_r = torch.from_numpy(ranks.astype(np.int64)).to("cuda:0")
+    d_q = torch.zeros((len(ranks), 4), dtype=torch.int32, device="cuda:0")
+    engine.unrank_dev(d_r.data_ptr(), len(ranks), d_q.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(d_q.cpu().numpy().view(np.uint32), want)
+
+
 def test_full_size_properties_c3(engine):
     """At BASELINE.json's c3 size (128 taxa, 50k SNPs): size-independent properties.
 
@@ -366,6 +381,37 @@ def test_pageable_and_pinned_result_arrays_agree(engine):
             np.testing.assert_array_equal(a, b)
     finally:
         engine.set_option("svd_chunk", 0)
+
+
+@pytest.mark.parametrize("Q", [65536, 100_000, 262_144, 262_145, 300_001])
+def test_pageable_results_mid_size_calls_default_chunking(engine, Q):
+    """Pageable result arrays at the DEFAULT singular-value chunking, for call sizes around the point where
+    stage_svd cuts one piece into two half-chunks on two streams (65 536 <= Q < 2 * svd_chunk): the drop-in
+    binding of INTEGRATION.md hands np.zeros arrays to tq_resolve at exactly such sizes (the reference's
+    get_chunksize gives 78 125-quartet chunks for 5e6 quartets on 4 cores, run_inference.py:73-96).
+    Every row must arrive, in its own slot, == the page-locked path."""
+    import ctypes
+    import torch
+    g = load_golden("c1_T16_S5000")
+    engine.set_data(g["tmparr"], g["tmpmap"])
+    base = g["quartets"]
+    q = np.ascontiguousarray(np.tile(base, (Q // len(base) + 1, 1))[:Q])
+    # make rows distinguishable by position: rotate the tiling so that row i != row i + Q/2 in general
+    q = np.ascontiguousarray(np.roll(q, 37, axis=0))
+    want = engine.resolve(q, True)                          # page-locked arrays (direct path)
+    assert want[0][:, 1].max() > 0
+    lib, h = engine._lib, engine._h
+    rstat, rscor, flags = np.full((Q, 2), 7, np.uint32), np.full((Q, 3), 7.0), np.full(Q, 7, np.uint8)
+    rc = lib.tq_resolve(h, ctypes.c_void_p(q.ctypes.data), Q, 1, ctypes.c_void_p(rstat.ctypes.data),
+                        ctypes.c_void_p(rscor.ctypes.data), ctypes.c_void_p(flags.ctypes.data))
+    assert rc == 0
+    for a, b in zip(want, (rstat, rscor, flags)):
+        np.testing.assert_array_equal(a, b)
+    dq = torch.from_numpy(q.astype(np.int32)).to("cuda:0")
+    out = (np.full((Q, 2), 9, np.uint32), np.full((Q, 3), 9.0), np.full(Q, 9, np.uint8))
+    engine.resolve_to_host(dq.data_ptr(), Q, True, out=out)
+    for a, b in zip(want, out):
+        np.testing.assert_array_equal(a, b)
 
 
 def test_scan_then_svd_in_pieces(engine):

@@ -128,6 +128,11 @@ struct tq_ctx {
     // host-buffer API: own compute and copy streams, events for the D2H pipeline
     hipStream_t sK = nullptr, sC = nullptr;
     std::vector<hipEvent_t> pipe_events;
+    // the asynchronous device API (caller's stream) and the synchronous host API (stream sK) share the count
+    // slab, the ordering scratch and the singular-value scratch: the last device-API enqueue records this event
+    // and the host API makes sK wait for it before it touches any of them
+    hipEvent_t evDevApi = nullptr;
+    bool dev_api_pending = false;
     // options
     int nrep = 1;
     int waves_per_cu = 0;           // 0 = from the occupancy query
@@ -604,6 +609,17 @@ int stage_scan(tq_ctx *ctx, const uint32_t *dq, int64_t n, int subsample, bool i
     return TQ_OK;
 }
 
+// Rows per chunk of the singular-value stage for a range of n rows (the ONE place that decides it: stage_svd
+// cuts by it and HostSink sizes its staging and picks its single-piece path by it).
+int64_t svd_chunk_rows(const tq_ctx *ctx, int64_t n)
+{
+    int64_t chunk = ctx->svd_chunk < n ? ctx->svd_chunk : n;
+    // a mid-size batch that would be one chunk is cut in two halves, one per stream: their tails fill each other
+    // (125k quartets 1.58 -> 1.53 ms, 300k 3.45 -> 3.35 ms) and the host API gets a result piece to copy early
+    if (ctx->svd_streams > 1 && n >= 65536 && n < 2 * ctx->svd_chunk && chunk > (n + 1) / 2) chunk = (n + 1) / 2;
+    return chunk < 1 ? 1 : chunk;
+}
+
 // Stage 2 of a pass: singular values, ranks, scores and topology of rows [q0, q0+n) of the scanned
 // batch, in chunks of svd_chunk quartets.  `out` points at the outputs of row q0.  Chunks alternate
 // between the caller's stream and a second one (each with its own scratch set), so that the tail of one
@@ -617,10 +633,7 @@ int stage_svd(tq_ctx *ctx, int64_t q0, int64_t n, bool debug, const OutPtrs &out
     if (q0 < 0 || n < 0 || q0 + n > ctx->scanned_Q)
         return fail(ctx, TQ_ERR_INVALID_ARG, "rows [%lld,+%lld) are outside the scanned batch of %lld quartets",
                     (long long)q0, (long long)n, (long long)ctx->scanned_Q);
-    int64_t chunk = ctx->svd_chunk < n ? ctx->svd_chunk : n;
-    // a mid-size batch that would be one chunk is cut in two halves, one per stream: their tails fill each other
-    // (125k quartets 1.58 -> 1.53 ms, 300k 3.45 -> 3.35 ms) and the host API gets a result piece to copy early
-    if (ctx->svd_streams > 1 && n >= 65536 && n < 2 * ctx->svd_chunk && chunk > (n + 1) / 2) chunk = (n + 1) / 2;
+    const int64_t chunk = svd_chunk_rows(ctx, n);
     int rc = ensure_svd(ctx, chunk);
     if (rc) return rc;
     const bool two = ctx->svd_streams > 1 && n > chunk;
@@ -684,10 +697,24 @@ size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 int ensure_streams(tq_ctx *ctx)
 {
-    if (ctx->sK) return TQ_OK;
-    TQ_HIP(ctx, hipStreamCreateWithFlags(&ctx->sK, hipStreamNonBlocking));
-    TQ_HIP(ctx, hipStreamCreateWithFlags(&ctx->sC, hipStreamNonBlocking));
+    if (!ctx->sK) {
+        TQ_HIP(ctx, hipStreamCreateWithFlags(&ctx->sK, hipStreamNonBlocking));
+        TQ_HIP(ctx, hipStreamCreateWithFlags(&ctx->sC, hipStreamNonBlocking));
+    }
+    if (ctx->dev_api_pending) {                  // work of the device API may still be using the shared scratch
+        TQ_HIP(ctx, hipStreamWaitEvent(ctx->sK, ctx->evDevApi, 0));
+        ctx->dev_api_pending = false;
+    }
     return TQ_OK;
+}
+
+// called after a device-API entry point has enqueued work on the caller's stream
+int note_dev_api(tq_ctx *ctx, hipStream_t stream, int rc)
+{
+    if (!ctx->evDevApi) TQ_HIP(ctx, hipEventCreateWithFlags(&ctx->evDevApi, hipEventDisableTiming));
+    TQ_HIP(ctx, hipEventRecord(ctx->evDevApi, stream));
+    ctx->dev_api_pending = true;
+    return rc;
 }
 
 int pipe_event(tq_ctx *ctx, size_t i, hipEvent_t *ev)
@@ -720,7 +747,7 @@ struct HostSink {
     bool single = false;           // pageable destinations, one piece: ONE D2H of the contiguous device region
     size_t off_rscor = 0, off_flags = 0;           // byte offsets of rscor / flags inside a staging piece
     char *stage[2] = {nullptr, nullptr};
-    int64_t stage_rows = 0;
+    int64_t stage_rows = 0, total_rows = 0;
     int64_t single_q0 = 0, single_n = 0;
     hipStream_t single_stream = nullptr;
     struct Pending { int64_t q0, n; hipEvent_t done; int buf; };
@@ -730,15 +757,23 @@ struct HostSink {
 
     int begin(int64_t Q)
     {
+        total_rows = Q;
         // (a call whose results fit one small piece is cheaper as ONE staged copy than as three direct ones)
         direct = (size_t)Q * 33 > ((size_t)1 << 20) && is_pinned(rstat, (size_t)Q * 8) &&
                  is_pinned(rscor, (size_t)Q * 24) && (!flags || is_pinned(flags, (size_t)Q));
         if (!direct) {
-            stage_rows = ctx->svd_chunk < Q ? ctx->svd_chunk : Q;
+            // what stage_svd will cut this call into: one scan batch of min(Q, batch) rows at a time, each in
+            // chunks of svd_chunk_rows(batch rows) -- the last batch may be shorter, never longer
+            const int64_t first_batch = Q < ctx->batch ? Q : ctx->batch;
+            stage_rows = svd_chunk_rows(ctx, first_batch);
+            if (Q > first_batch) {
+                const int64_t tail = svd_chunk_rows(ctx, Q % first_batch ? Q % first_batch : first_batch);
+                if (tail > stage_rows) stage_rows = tail;
+            }
             // small calls (the reference's distributor hands out chunks of a few thousand quartets,
-            // run_inference.py:73-96) are dominated by the number of HIP calls: when the whole call is one
-            // piece, the device outputs [rstat | rscor | flags] are one contiguous region -> one copy
-            single = Q <= ctx->svd_chunk && Q <= ctx->batch && dev->flags &&
+            // run_inference.py:73-96) are dominated by the number of HIP calls: when the whole call is ONE
+            // chunk, the device outputs [rstat | rscor | flags] are one contiguous region -> one copy
+            single = Q <= ctx->batch && stage_rows >= Q && dev->flags &&
                      (const char *)dev->rscor > (const char *)dev->rstat && (const char *)dev->flags > (const char *)dev->rscor;
             off_rscor = single ? (size_t)((const char *)dev->rscor - (const char *)dev->rstat) : (size_t)stage_rows * 8;
             off_flags = single ? (size_t)((const char *)dev->flags - (const char *)dev->rstat) : (size_t)stage_rows * 32;
@@ -764,10 +799,16 @@ struct HostSink {
     // the kernels of chunk [q0, q0+n) have been enqueued on `st`
     int chunk(int64_t q0, int64_t n, hipStream_t st)
     {
+        if (!direct && n > stage_rows)
+            return fail(ctx, TQ_ERR_HIP, "internal: result chunk of %lld rows exceeds the staging piece of %lld",
+                        (long long)n, (long long)stage_rows);
         if (single) {
             // one piece, one copy, nothing to overlap with: the copy goes behind the kernels on their own stream
             // and finish() waits for that stream -- no events, no second stream (a 1 000-quartet call is a
             // dozen HIP calls; every one of them shows)
+            if (q0 != 0 || n != total_rows || nchunk != 0)
+                return fail(ctx, TQ_ERR_HIP, "internal: single-piece result path got chunk [%lld,+%lld) of %lld rows",
+                            (long long)q0, (long long)n, (long long)total_rows);
             TQ_HIP(ctx, hipMemcpyAsync(stage[0], dev->rstat, off_flags + (size_t)n, hipMemcpyDeviceToHost, st));
             single_q0 = q0;
             single_n = n;
@@ -903,6 +944,7 @@ void tq_destroy(tq_ctx *ctx)
         (void)hipEventDestroy(ctx->evFork);
         (void)hipEventDestroy(ctx->evJoin);
     }
+    if (ctx->evDevApi) (void)hipEventDestroy(ctx->evDevApi);
     for (auto e : ctx->pipe_events) (void)hipEventDestroy(e);
     for (auto &m : ctx->marks) (void)hipEventDestroy(m.ev);
     for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
@@ -962,16 +1004,21 @@ int tq_set_data(tq_ctx *ctx, const uint8_t *tmparr, int64_t T, int64_t S, const 
     ctx->data_capacity = Sp;
     uint8_t *d_raw = nullptr;
     uint32_t *d_loc = nullptr;
-    TQ_HIP(ctx, hipMalloc((void **)&ctx->d_rows, (size_t)(T * Sp)));
-    TQ_HIP(ctx, hipMalloc((void **)&ctx->d_nib, (size_t)(T * Sp / 2)));
-    TQ_HIP(ctx, hipMalloc((void **)&ctx->d_planes, (size_t)(T * W) * sizeof(uint4)));
-    TQ_HIP(ctx, hipMalloc((void **)&ctx->d_planes3, (size_t)(T * W * 3 + W) * sizeof(uint32_t)));
+    // every allocation of this call is released on every failure path (the resident arrays by free_data,
+    // the two upload temporaries here)
+    hipError_t e = hipMalloc((void **)&ctx->d_rows, (size_t)(T * Sp));
+    if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_nib, (size_t)(T * Sp / 2));
+    if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_planes, (size_t)(T * W) * sizeof(uint4));
+    if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_planes3, (size_t)(T * W * 3 + W) * sizeof(uint32_t));
     ctx->plane_cap_W = W;
-    TQ_HIP(ctx, hipMalloc((void **)&d_raw, (size_t)(T * S)));
-    hipError_t e = hipMalloc((void **)&d_loc, (size_t)S * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMalloc((void **)&d_raw, (size_t)(T * S));
+    if (e == hipSuccess) e = hipMalloc((void **)&d_loc, (size_t)S * sizeof(uint32_t));
     if (e != hipSuccess) {
-        (void)hipFree(d_raw);
-        return fail(ctx, TQ_ERR_OOM, "hipMalloc(locus) failed: %s", hipGetErrorString(e));
+        if (d_raw) (void)hipFree(d_raw);
+        if (d_loc) (void)hipFree(d_loc);
+        free_data(ctx);
+        return fail(ctx, e == hipErrorOutOfMemory ? TQ_ERR_OOM : TQ_ERR_HIP, "tq_set_data: hipMalloc failed: %s",
+                    hipGetErrorString(e));
     }
     e = hipMemcpy(d_raw, tmparr, (size_t)(T * S), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(d_loc, loc.data(), (size_t)S * sizeof(uint32_t), hipMemcpyHostToDevice);
@@ -1002,7 +1049,8 @@ int tq_resolve_dev(tq_ctx *ctx, const uint32_t *d_quartets, int64_t Q, int subsa
         return fail(ctx, TQ_ERR_INVALID_ARG, "tq_resolve_dev: NULL pointer or negative Q");
     TQ_HIP(ctx, hipSetDevice(ctx->device));
     OutPtrs out{d_rstat, d_rscor, d_flags, nullptr, nullptr, nullptr};
-    return launch(ctx, d_quartets, Q, subsample, false, false, out, (hipStream_t)stream, NoChunkHook());
+    return note_dev_api(ctx, (hipStream_t)stream,
+                        launch(ctx, d_quartets, Q, subsample, false, false, out, (hipStream_t)stream, NoChunkHook()));
 }
 
 int tq_scan_dev(tq_ctx *ctx, const uint32_t *d_quartets, int64_t Q, int subsample, void *stream)
@@ -1016,7 +1064,7 @@ int tq_scan_dev(tq_ctx *ctx, const uint32_t *d_quartets, int64_t Q, int subsampl
     if (rc) return rc;
     TQ_HIP(ctx, hipSetDevice(ctx->device));
     if (ctx->timing) ctx->timed_calls++;
-    return stage_scan(ctx, d_quartets, Q, subsample, false, (hipStream_t)stream);
+    return note_dev_api(ctx, (hipStream_t)stream, stage_scan(ctx, d_quartets, Q, subsample, false, (hipStream_t)stream));
 }
 
 int tq_svd_dev(tq_ctx *ctx, int64_t q0, int64_t n, uint32_t *d_rstat, double *d_rscor, uint8_t *d_flags, void *stream)
@@ -1028,7 +1076,7 @@ int tq_svd_dev(tq_ctx *ctx, int64_t q0, int64_t n, uint32_t *d_rstat, double *d_
     if (n == 0) return TQ_OK;
     TQ_HIP(ctx, hipSetDevice(ctx->device));
     OutPtrs out{d_rstat, d_rscor, d_flags, nullptr, nullptr, nullptr};
-    return stage_svd(ctx, q0, n, false, out, (hipStream_t)stream, NoChunkHook());
+    return note_dev_api(ctx, (hipStream_t)stream, stage_svd(ctx, q0, n, false, out, (hipStream_t)stream, NoChunkHook()));
 }
 
 int tq_unrank_dev(tq_ctx *ctx, const uint64_t *d_ranks, int64_t Q, uint32_t *d_quartets, void *stream)
@@ -1070,7 +1118,8 @@ int tq_resolve_range_dev(tq_ctx *ctx, uint64_t first_rank, int64_t Q, int subsam
     TQ_HIP(ctx, hipGetLastError());
     OutPtrs out{d_rstat, d_rscor, d_flags, nullptr, nullptr, nullptr};
     // consecutive lexicographic ranks are in (a,b,c) order already
-    return launch(ctx, dq, Q, subsample, false, true, out, (hipStream_t)stream, NoChunkHook());
+    return note_dev_api(ctx, (hipStream_t)stream,
+                        launch(ctx, dq, Q, subsample, false, true, out, (hipStream_t)stream, NoChunkHook()));
 }
 
 int tq_resolve_to_host(tq_ctx *ctx, const uint32_t *d_quartets, int64_t Q, int subsample, uint32_t *rstat,
@@ -1440,7 +1489,7 @@ int tq_bootstrap_async(tq_ctx *ctx, const int64_t *lidxs, int64_t n, uint64_t se
     ctx->locus_runs_ok = true;          // locus ids are the ordinals 0..n-1, one run each
     ctx->scanned_Q = 0;
     if (out_S) *out_S = S;
-    return TQ_OK;
+    return note_dev_api(ctx, stream, TQ_OK);       // the host API must not scan a half-built replicate
 }
 
 int tq_bootstrap(tq_ctx *ctx, const int64_t *lidxs, int64_t n, uint64_t seed_shuffle, uint64_t seed_ambig,

@@ -344,8 +344,12 @@ def resolve_sharded(tmparr, tmpmap, quartets, subsample_snps: bool = True, *, gr
         dev_id = torch.cuda.current_device() if device is None else torch.device(device).index
         eng = get_engine(dev_id)
         _ensure_resident(eng, tmparr, tmpmap)
-        key = (Q, world, dev_id, dst, pieces, id(group))
+        key = (Q, world, dev_id, dst, pieces)
         res = _resolvers.get("res") if _resolvers.get("key") == key else None
+        # the cached resolver is only good for the SAME live engine and process group objects (an id() can be
+        # re-used by a new group after the old one is destroyed; get_engine may hand out a fresh engine after close)
+        if res is not None and not (res.engine is eng and res.group is group):
+            res = None
         if res is None:                                  # buffers are kept for the next batch of this size
             res = ShardedResolver(Q, engine=eng, group=group, device=dev_id, dst=dst, pieces=pieces)
             _resolvers.update(key=key, res=res)

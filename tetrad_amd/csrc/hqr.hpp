@@ -346,7 +346,8 @@ tq_bdsqr_kernel(const double *__restrict__ de, int64_t nmat, double *__restrict_
 #undef SET_E
 #undef SET_W
         if (stats) {
-            // wave_iters is only meaningful on lanes that took part in every sweep of the wave: take the maximum
+            // a lane takes part in every sweep of the wave until its own matrix is done, so its wave_iters is what
+            // the wave had issued when it finished; the maximum over the lanes is what the wave issued in all
             uint32_t wi = wave_iters;
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) wi = max(wi, (uint32_t)__shfl_xor((int)wi, o, WAVE));
@@ -354,6 +355,7 @@ tq_bdsqr_kernel(const double *__restrict__ de, int64_t nmat, double *__restrict_
                 atomicAdd(&stats[0], 1ull);
                 atomicAdd(&stats[1], (unsigned long long)my_steps);
                 atomicAdd(&stats[3], (unsigned long long)my_sweeps);
+                atomicAdd(&stats[4], (unsigned long long)(wi - wave_iters));     // slots after this lane's matrix was done
             }
             if (lane == 0) atomicAdd(&stats[2], 64ull * wi);
         }

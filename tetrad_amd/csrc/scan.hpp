@@ -43,25 +43,39 @@ template <bool SUB>
 __device__ __forceinline__ uint32_t count_from_candidates(uint32_t U, uint32_t B, int lane, uint32_t &tile_carry)
 {
     if (!SUB) return U;
+    (void)lane;
     const uint32_t P = ~B;
     const uint32_t X = U | P;
-    const uint32_t sum = X + U;
+    // in-lane: X + U; its carry-out IS t(31), so the per-lane "generate" flags of the lane-to-lane chain come out of
+    // the add itself as a 64-bit lane mask (the sdst of v_add_co_u32) -- no bit fiddling, no compare, no ballot
+    uint32_t sum;
+    uint64_t Gm;
+    asm("v_add_co_u32_e64 %0, %1, %2, %3" : "=v"(sum), "=s"(Gm) : "v"(X), "v"(U));
     const uint32_t cin0 = sum ^ X ^ U;                       // carry into each bit, lane carry-in = 0
     const uint32_t seen_local = P & cin0;
-    const uint32_t gen = ((X & U) | ((X | U) & ~sum)) >> 31; // carry out of bit 31 = t(31)
-    // cross-lane: T(l) = gen(l) | (allprop(l) & T(l-1)); same adder trick on 64-bit ballots (SALU)
-    const uint64_t Gm = __ballot(gen != 0);
+    // cross-lane: T(l) = gen(l) | (allprop(l) & T(l-1)): the same adder trick on two 64-bit lane masks, one full
+    // adder on the scalar unit -- carry-in = the carry out of the previous 2048-site step, put into SCC; the carry
+    // out of lane 63 is the SCC the second s_addc leaves (the compiler's own u64 add-with-overflow compares on the
+    // vector unit and keeps the step-to-step carry in a VGPR)
     const uint64_t Pm = __ballot(B == 0);
     const uint64_t Xm = Gm | Pm;
-    const uint64_t s1 = Xm + Gm;
-    const uint64_t s2 = s1 + (uint64_t)tile_carry;
-    const uint64_t cinm = s2 ^ Xm ^ Gm;                      // carry into each lane
-    tile_carry = (uint32_t)((s1 < Xm) | (s2 < s1));          // carry out of lane 63
-    const uint32_t cin = (uint32_t)(cinm >> lane) & 1u;
-    // sites before this lane's first run-begin inherit the incoming "seen" state
-    const uint32_t firstseg = B ? ((B & (0u - B)) - 1u) : 0xFFFFFFFFu;
-    const uint32_t seen = seen_local | (cin ? firstseg : 0u);
-    return U & ~seen;
+    uint32_t lo, hi, cout;
+    asm("s_cmp_lg_u32 %3, 0\n\t"
+        "s_addc_u32 %0, %4, %6\n\t"
+        "s_addc_u32 %1, %5, %7\n\t"
+        "s_cselect_b32 %2, 1, 0"
+        : "=&s"(lo), "=&s"(hi), "=s"(cout)
+        : "s"(__builtin_amdgcn_readfirstlane(tile_carry)), "s"((uint32_t)Xm), "s"((uint32_t)(Xm >> 32)), "s"((uint32_t)Gm), "s"((uint32_t)(Gm >> 32))
+        : "scc");
+    const uint64_t cinm = (((uint64_t)hi << 32) | lo) ^ Xm ^ Gm;      // carry into each lane: bit l = lane l inherits "seen"
+    tile_carry = cout;                                       // carry out of lane 63
+    // sites before this lane's first run-begin inherit the incoming "seen" state: B | -B marks the first run-begin
+    // and everything above it (0 when the lane has none), its complement is that first segment
+    const uint32_t notfirst = B | (0u - B);
+    // cinm is used as what it is -- a lane mask -- by one v_cndmask (the compiler would shift it by the lane id)
+    uint32_t inherit;
+    asm("v_cndmask_b32_e64 %0, -1, %1, %2" : "=v"(inherit) : "v"(notfirst), "s"(cinm));      // cin ? notfirst : ~0
+    return U & ~seen_local & inherit;                        // = U & ~(seen_local | (cin ? ~notfirst : 0))
 }
 
 template <bool SUB>
@@ -94,6 +108,108 @@ constexpr int PAT_STRIDE = 36;   // bytes per lane in the pattern park: 9 dwords
                                  // two b128 stores is cheaper in isolation, tools/probe_lds.hip, but 14 % slower here:
                                  // the first counted sites of neighbouring lanes tend to have similar indices)
 
+// LDS byte offset of a __shared__ object (the low half of its flat address: the LDS aperture is 4 GiB aligned)
+__device__ __forceinline__ uint32_t lds_offset(const void *p) { return (uint32_t)(uintptr_t)p; }
+
+// The set-bit walk of METHOD 1: for every set bit i of `c`, hist[park[i]] += 1 (park = the lane's 32 parked pattern
+// bytes, hist = the wave's 256 u32 bins; both given as LDS byte offsets).  Hand-written because the loop is half of
+// the scan kernel's vector instructions and the compiler's version spends 6.3 of them per counted site (plus a dozen
+// scalar ones for its two-phase control flow); this one spends 5:
+//   v_ffbl (index of the lowest set bit) . v_and (clear it, with c-1 from the previous trip) . v_add (byte address)
+//   . v_add_co (c-1 for the next trip AND "c != 0" as its carry-out: adding 0xFFFFFFFF carries iff c >= 1)
+//   . v_lshl_add (bin address)
+// and leaves the loop by and-ing EXEC with that carry mask on the scalar unit.  The wave runs for its longest lane
+// (8.2 trips against a mean of 5.6 counted sites on c3); LDS operations of one wave execute in order, so the byte
+// read sees the park stores issued just before without a wait.
+// TRANSPOSED park: the wave's 8 pattern dwords per lane are stored row-major [dword j][lane] (256-byte rows), so a
+// byte read touches bank (lane mod 32) whatever its site index -- conflict-free, where the lane-contiguous layout
+// (stride 36 bytes) pays 2.5 extra LDS cycles per read instruction on c3 (rocprofv3: SQ_LDS_BANK_CONFLICT of the
+// walk without atomics) -- at the price of two more vector instructions per counted site for the address
+// lanebase + (i >> 2) * 256 + (i & 3) = (lanebase + i) + (i >> 2) * 252.
+template <bool ATOMICS = true, bool TRANSPOSED = false>
+__device__ __forceinline__ void walk_set_bits(uint32_t c, uint32_t park_off, uint32_t hist_off)
+{
+    if (ATOMICS && TRANSPOSED) {
+        uint32_t t, i, j, b;
+        uint64_t save;
+        uint32_t one = 1u, k252 = 252u;
+        asm volatile(
+            "s_mov_b64 %[save], exec\n\t"
+            "v_add_co_u32_e32 %[t], vcc, -1, %[c]\n\t"
+            "s_and_b64 exec, exec, vcc\n\t"
+            "s_cbranch_execz 1f\n"
+            "0:\n\t"
+            "v_ffbl_b32_e32 %[i], %[c]\n\t"
+            "v_and_b32_e32 %[c], %[c], %[t]\n\t"
+            "v_lshrrev_b32_e32 %[j], 2, %[i]\n\t"
+            "v_add_u32_e32 %[i], %[park], %[i]\n\t"
+            "v_mad_u32_u24 %[i], %[j], %[k252], %[i]\n\t"
+            "ds_read_u8 %[b], %[i]\n\t"
+            "v_add_co_u32_e32 %[t], vcc, -1, %[c]\n\t"
+            "s_waitcnt lgkmcnt(0)\n\t"
+            "v_lshl_add_u32 %[b], %[b], 2, %[hist]\n\t"
+            "ds_add_u32 %[b], %[one]\n\t"
+            "s_and_b64 exec, exec, vcc\n\t"
+            "s_cbranch_execnz 0b\n"
+            "1:\n\t"
+            "s_mov_b64 exec, %[save]"
+            : [c] "+v"(c), [t] "=&v"(t), [i] "=&v"(i), [j] "=&v"(j), [b] "=&v"(b), [save] "=&s"(save)
+            : [park] "v"(park_off), [hist] "s"(hist_off), [one] "v"(one), [k252] "s"(k252)
+            : "vcc", "memory");
+        return;
+    }
+    if (!ATOMICS) {          // timing diagnostic (METHOD 4): the walk and its byte reads without the histogram increments
+        uint32_t t, i, b, acc = 0;
+        uint64_t save;
+        asm volatile(
+            "s_mov_b64 %[save], exec\n\t"
+            "v_add_co_u32_e32 %[t], vcc, -1, %[c]\n\t"
+            "s_and_b64 exec, exec, vcc\n\t"
+            "s_cbranch_execz 1f\n"
+            "0:\n\t"
+            "v_ffbl_b32_e32 %[i], %[c]\n\t"
+            "v_and_b32_e32 %[c], %[c], %[t]\n\t"
+            "v_add_u32_e32 %[i], %[park], %[i]\n\t"
+            "ds_read_u8 %[b], %[i]\n\t"
+            "v_add_co_u32_e32 %[t], vcc, -1, %[c]\n\t"
+            "s_waitcnt lgkmcnt(0)\n\t"
+            "v_lshl_add_u32 %[acc], %[b], 2, %[acc]\n\t"
+            "s_and_b64 exec, exec, vcc\n\t"
+            "s_cbranch_execnz 0b\n"
+            "1:\n\t"
+            "s_mov_b64 exec, %[save]"
+            : [c] "+v"(c), [t] "=&v"(t), [i] "=&v"(i), [b] "=&v"(b), [save] "=&s"(save), [acc] "+v"(acc)
+            : [park] "v"(park_off)
+            : "vcc", "memory");
+        asm volatile("" ::"v"(acc));
+        return;
+    }
+    uint32_t t, i, b;
+    uint64_t save;
+    uint32_t one = 1u;
+    asm volatile(
+        "s_mov_b64 %[save], exec\n\t"
+        "v_add_co_u32_e32 %[t], vcc, -1, %[c]\n\t"
+        "s_and_b64 exec, exec, vcc\n\t"
+        "s_cbranch_execz 1f\n"
+        "0:\n\t"
+        "v_ffbl_b32_e32 %[i], %[c]\n\t"
+        "v_and_b32_e32 %[c], %[c], %[t]\n\t"
+        "v_add_u32_e32 %[i], %[park], %[i]\n\t"
+        "ds_read_u8 %[b], %[i]\n\t"
+        "v_add_co_u32_e32 %[t], vcc, -1, %[c]\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "v_lshl_add_u32 %[b], %[b], 2, %[hist]\n\t"
+        "ds_add_u32 %[b], %[one]\n\t"
+        "s_and_b64 exec, exec, vcc\n\t"
+        "s_cbranch_execnz 0b\n"
+        "1:\n\t"
+        "s_mov_b64 exec, %[save]"
+        : [c] "+v"(c), [t] "=&v"(t), [i] "=&v"(i), [b] "=&v"(b), [save] "=&s"(save)
+        : [park] "v"(park_off), [hist] "s"(hist_off), [one] "v"(one)
+        : "vcc", "memory");
+}
+
 // pat[j] holds the 8-bit patterns (a<<6|b<<4|c<<2|d) of sites 4j..4j+3 of this lane, one per byte
 struct NoHook {
     __device__ __forceinline__ void operator()() const {}
@@ -102,11 +218,16 @@ struct NoHook {
 // `after_build` runs once the patterns are in their final place (registers for METHOD 0, the LDS park
 // for METHOD 1) and before the histogram increments: the cooperative kernel issues the next step's
 // row loads there, so that they fly under the increments and need no second register set.
-template <int NREP, int METHOD, typename Hook = NoHook>
+template <int NREP, int METHOD, typename Hook = NoHook, bool PARK_T = false>
 __device__ __forceinline__ void hist_patterns(const uint32_t (&pat)[8], uint32_t C, uint32_t *hrep, uint8_t *park,
                                               Hook after_build = Hook())
 {
-    if (METHOD == 2) {
+    if (METHOD == 2 || METHOD == 5) {
+        if (METHOD == 5) {               // timing diagnostic: the park stores, no walk
+            uint32_t *pw = reinterpret_cast<uint32_t *>(park);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) pw[j] = pat[j];
+        }
         uint32_t acc = C;
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc ^= pat[j];
@@ -126,32 +247,17 @@ __device__ __forceinline__ void hist_patterns(const uint32_t (&pat)[8], uint32_t
     } else {
         uint32_t *pw = reinterpret_cast<uint32_t *>(park);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) pw[j] = pat[j];
+        for (int j = 0; j < 8; ++j) pw[PARK_T ? j * WAVE : j] = pat[j];     // PARK_T: `park` = row 0 of the wave + lane * 4
         after_build();
-        // set-bit walk, software pipelined: the pattern byte of the NEXT counted site is requested
-        // before the histogram increment of the current one (two alternating registers: a copy
-        // would wait for the read it copies)
-        uint32_t c = C;
-        if (c) {
-            // the loop carries the bin's address (a full 32-bit value: a loop-carried byte would be
-            // re-masked with 0xff at every use)
-            uint32_t *p0 = hrep + (uint32_t)park[__builtin_ctz(c)] * NREP, *p1 = nullptr;
-            c &= c - 1;
-            for (;;) {
-                if (!c) {
-                    __hip_atomic_fetch_add(p0, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    break;
-                }
-                p1 = hrep + (uint32_t)park[__builtin_ctz(c)] * NREP;
+        if (NREP == 1) {
+            walk_set_bits<METHOD != 4, PARK_T>(C, lds_offset(park), lds_offset(hrep));
+        } else {
+            // set-bit walk (replicated histograms: the one-wave-per-quartet kernel's A/B option)
+            uint32_t c = C;
+            while (c) {
+                uint32_t *p0 = hrep + (uint32_t)park[__builtin_ctz(c)] * NREP;
                 c &= c - 1;
                 __hip_atomic_fetch_add(p0, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                if (!c) {
-                    __hip_atomic_fetch_add(p1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    break;
-                }
-                p0 = hrep + (uint32_t)park[__builtin_ctz(c)] * NREP;
-                c &= c - 1;
-                __hip_atomic_fetch_add(p1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
         }
     }
@@ -335,7 +441,7 @@ constexpr int SHARED_SLOTS = 208;
 // L2 save: the kernel is not bound by bytes.  Off by default (option "share_c"), parity-tested.
 constexpr int SHARED_SLOTS_C = SHARED_SLOTS + 128;
 
-template <bool SUB, int METHOD, int NW, bool SHC = false>
+template <bool SUB, int METHOD, int NW, bool SHC = false, bool PARK_T = false>
 __global__ void __launch_bounds__(NW *WAVE)
 tq_scan_wg_kernel(DevData d, const uint32_t *__restrict__ quartets, const uint32_t *__restrict__ order, int64_t Q,
                   uint32_t *__restrict__ cm, int64_t xcd_chunk)
@@ -343,13 +449,19 @@ tq_scan_wg_kernel(DevData d, const uint32_t *__restrict__ quartets, const uint32
     static_assert(NW >= 1 && NW <= 16, "waves per workgroup");
     static_assert(!SHC || NW >= 4, "the row-c job needs a fourth wave");
     __shared__ uint4 shared_ab[2][SHC ? SHARED_SLOTS_C : SHARED_SLOTS];
+    // (two copies of the wave's histogram, odd and even lanes apart, were measured: SQ_LDS_ADDR_CONFLICT 563M -> 350M
+    // per dispatch, SQ_LDS_BANK_CONFLICT and the LDS-busy cycles unchanged to the digit, 6.42 -> 6.58 ms with the lower
+    // occupancy -- profiles/r03_scan/)
     __shared__ uint32_t hist_all[NW][256];
-    __shared__ uint32_t park_all[NW][WAVE * PAT_STRIDE / 4];
+    __shared__ uint32_t park_all[NW][PARK_T ? WAVE * 8 : WAVE * PAT_STRIDE / 4];
     const int tid = threadIdx.x;
-    const int w = tid >> 6;
+    // the wave's number as a scalar: everything derived from it (does this wave have a quartet, does it share the
+    // leader's rows, its histogram) is then wave-uniform for the compiler too -- scalar branches instead of EXEC
+    // masking, and the step-to-step carry of subsample mode stays in an SGPR
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63;
     uint32_t *hist = hist_all[w];
-    uint8_t *park = reinterpret_cast<uint8_t *>(park_all[w]) + lane * PAT_STRIDE;
+    uint8_t *park = reinterpret_cast<uint8_t *>(park_all[w]) + lane * (PARK_T ? 4 : PAT_STRIDE);
     for (int i = lane; i < 256; i += WAVE) hist[i] = 0;
     const uint32_t T = (uint32_t)d.T;
     const int last = d.ntiles - 1;
@@ -529,10 +641,11 @@ tq_scan_wg_kernel(DevData d, const uint32_t *__restrict__ quartets, const uint32
             pat[2] = and_or(s1, m, ab0.z); pat[3] = and_or(s1 >> 4, m, ab0.w);
             pat[4] = and_or(s2, m, ab1.x); pat[5] = and_or(s2 >> 4, m, ab1.y);
             pat[6] = and_or(s3, m, ab1.z); pat[7] = and_or(s3 >> 4, m, ab1.w);
-            hist_patterns<1, METHOD == 3 ? 1 : METHOD>(pat, C, hist, park, [&]() {
+            auto hook = [&]() {
                 load_mine(own, tnext);
                 __builtin_amdgcn_sched_barrier(0);
-            });
+            };
+            hist_patterns<1, METHOD == 3 ? 1 : METHOD, decltype(hook), PARK_T>(pat, C, hist, park, hook);
         };
 
         for (int t = 0; t < d.ntiles; ++t) {

@@ -119,6 +119,8 @@ struct tq_ctx {
                                          // lane-slots issued (64 x wave iterations), sweeps} summed over the launches
     int scan_wg = 4;                // waves per workgroup of the cooperative scan kernel (1 = one wave per quartet)
     int xcd_remap = 1;              // 1: scan workgroups of one XCD take a contiguous part of the sorted order
+    int park_t = 1;                 // 1 (default): transposed pattern park of the set-bit walk (conflict-free byte reads at the price of
+                                    // 2 more VALU per counted site: c3 6.79 -> 6.42 ms); 0: lane-contiguous park (A/B)
     int share_c = 0;                // 1: scan kernel variant that also shares row c inside a workgroup (scan.hpp: SHC;
                                     // measured slower everywhere -- the kernel is LDS/VALU-bound, not byte-bound -- kept as an A/B option)
     int svd_wpc = 0;                // blocks per CU of the bidiag / bdsqr grids (0 = one pass per block)
@@ -446,10 +448,10 @@ int launch_scan(tq_ctx *ctx, const uint32_t *dq, const uint32_t *order, int64_t 
     return TQ_OK;
 }
 
-template <bool SUB, int METHOD, int NW, bool SHC = false>
+template <bool SUB, int METHOD, int NW, bool SHC = false, bool PARK_T = false>
 int launch_scan_wg(tq_ctx *ctx, const uint32_t *dq, const uint32_t *order, int64_t Q, hipStream_t stream)
 {
-    auto kern = tq_scan_wg_kernel<SUB, METHOD, NW, SHC>;
+    auto kern = tq_scan_wg_kernel<SUB, METHOD, NW, SHC, PARK_T>;
     const int wgs = ctx->waves_per_cu > 0 ? (ctx->waves_per_cu + NW - 1) / NW : 0;
     // default: one block of NW quartets per workgroup, dispatched in sorted order.  Workgroups that
     // run at the same time are then neighbours of the (a,b) order (their shared rows are L2 hits) and
@@ -480,6 +482,8 @@ int launch_scan_n(tq_ctx *ctx, const uint32_t *dq, const uint32_t *order, int64_
     if (ctx->scan_wg == NW) {                                                                            \
         if (m == 2) return launch_scan_wg<true, 2, NW>(ctx, dq, order, Q, stream);                       \
         if (m == 3) return launch_scan_wg<true, 3, NW>(ctx, dq, order, Q, stream);                       \
+        if (NW == 4 && m == 4) return launch_scan_wg<true, 4, 4>(ctx, dq, order, Q, stream);             \
+        if (NW == 4 && m == 5) return launch_scan_wg<true, 5, 4>(ctx, dq, order, Q, stream);             \
         if (subsample)                                                                                   \
             return m ? launch_scan_wg<true, 1, NW>(ctx, dq, order, Q, stream)                            \
                      : launch_scan_wg<true, 0, NW>(ctx, dq, order, Q, stream);                           \
@@ -487,6 +491,9 @@ int launch_scan_n(tq_ctx *ctx, const uint32_t *dq, const uint32_t *order, int64_
                  : launch_scan_wg<false, 0, NW>(ctx, dq, order, Q, stream);                              \
     }
         TQ_WG_CASE(2)
+        if (ctx->scan_wg == 4 && ctx->park_t && m == 1 && !ctx->share_c)
+            return subsample ? launch_scan_wg<true, 1, 4, false, true>(ctx, dq, order, Q, stream)
+                             : launch_scan_wg<false, 1, 4, false, true>(ctx, dq, order, Q, stream);
         if (ctx->scan_wg == 4 && ctx->share_c && m <= 1) {
             if (subsample)
                 return m ? launch_scan_wg<true, 1, 4, true>(ctx, dq, order, Q, stream)
@@ -1301,6 +1308,10 @@ int tq_set_option(tq_ctx *ctx, const char *name, int64_t value)
         ctx->xcd_remap = value != 0;
         return TQ_OK;
     }
+    if (!strcmp(name, "park_t")) {
+        ctx->park_t = value != 0;
+        return TQ_OK;
+    }
     if (!strcmp(name, "share_c")) {
         ctx->share_c = value != 0;
         return TQ_OK;
@@ -1324,8 +1335,8 @@ int tq_set_option(tq_ctx *ctx, const char *name, int64_t value)
         if (ctx->d_bdsqr_stats) (void)hipFree(ctx->d_bdsqr_stats);
         ctx->d_bdsqr_stats = nullptr;
         if (value) {
-            TQ_HIP(ctx, hipMalloc((void **)&ctx->d_bdsqr_stats, 4 * sizeof(uint64_t)));
-            TQ_HIP(ctx, hipMemset(ctx->d_bdsqr_stats, 0, 4 * sizeof(uint64_t)));
+            TQ_HIP(ctx, hipMalloc((void **)&ctx->d_bdsqr_stats, 8 * sizeof(uint64_t)));
+            TQ_HIP(ctx, hipMemset(ctx->d_bdsqr_stats, 0, 8 * sizeof(uint64_t)));
         }
         return TQ_OK;
     }
@@ -1351,8 +1362,8 @@ int tq_set_option(tq_ctx *ctx, const char *name, int64_t value)
         return TQ_OK;
     }
     if (!strcmp(name, "scan_method")) {
-        if (value != 0 && value != 1 && value != -1 && value != 2 && value != 3)
-            return fail(ctx, TQ_ERR_INVALID_ARG, "scan_method must be -1 (auto), 0, 1 (or 2, 3: timing diagnostics)");
+        if (value < -1 || value > 5)
+            return fail(ctx, TQ_ERR_INVALID_ARG, "scan_method must be -1 (auto), 0, 1 (or 2..5: timing diagnostics)");
         ctx->scan_method = (int)value;
         return TQ_OK;
     }

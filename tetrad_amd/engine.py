@@ -247,7 +247,7 @@ class QuartetEngine:
     def debug_fetch(self, which: str, n: int) -> np.ndarray:
         """Scratch of the last resolve call (test hook): 'cm' u32[n,256], 'de' f64[3n,32], 'sv' f64[3n,16]."""
         shape, dt, code = {"cm": ((n, 256), np.uint32, 0), "de": ((3 * n, 32), np.float64, 1),
-                           "sv": ((3 * n, 16), np.float64, 2), "bdsqr_stats": ((4,), np.uint64, 3)}[which]
+                           "sv": ((3 * n, 16), np.float64, 2), "bdsqr_stats": ((8,), np.uint64, 3)}[which]
         out = np.zeros(shape, dt)
         self._check(self._lib.tq_debug_fetch(self._h, code, _ptr(out), out.nbytes))
         return out

@@ -36,7 +36,11 @@
     X(30, "v_cmp_gt_f64", "v_cmp_gt_f64 vcc, %0, %1") \
     X(31, "v_mov_b32 dpp quad_perm", "v_mov_b32_dpp %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf") \
     X(32, "v_max_f64", "v_max_f64 %0, %0, %1") \
-    X(33, "v_cvt_f64_u32", "v_cvt_f64_u32 %0, %2")
+    X(33, "v_cvt_f64_u32", "v_cvt_f64_u32 %0, %2") \
+    X(34, "v_cndmask_b32 (sgpr pair)", "v_cndmask_b32_e64 %0, %0, %1, %2") \
+    X(35, "v_cmp_lt_u32 + v_cndmask (vcc)", "v_cmp_lt_u32 vcc, %0, %1\n v_cndmask_b32 %0, %0, %1, vcc") \
+    X(36, "v_add_co_u32 (vcc out)", "v_add_co_u32 %0, vcc, %0, %1") \
+    X(37, "ds_read_u8 + wait", "ds_read_u8 %0, %0\n s_waitcnt lgkmcnt(0)")
 
 template <int KIND>
 __global__ void k(unsigned *out, int iters)
@@ -46,6 +50,7 @@ __global__ void k(unsigned *out, int iters)
     for (int i = 0; i < 8; ++i) { a[i] = threadIdx.x * 7 + i; d[i] = 1.0 + threadIdx.x * 1e-3 + i; }
     unsigned b = threadIdx.x | 1;
     double bd = 1.0000001;
+    const unsigned long long smask = 0x5555aaaa5555aaaaull ^ (unsigned long long)iters;
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
@@ -53,8 +58,10 @@ __global__ void k(unsigned *out, int iters)
             for (int i = 0; i < 8; ++i) {
 #define X(ID, NAME, ASM) \
     if (KIND == ID) { \
-        if (ID >= 25 && ID != 31 && ID != 33) asm volatile(ASM : "+v"(d[i]) : "v"(bd) : "vcc"); \
+        if (ID >= 25 && ID <= 32 && ID != 31) asm volatile(ASM : "+v"(d[i]) : "v"(bd) : "vcc"); \
         else if (ID == 33) asm volatile(ASM : "+v"(d[i]) : "v"(bd), "v"(a[i]) : "vcc"); \
+        else if (ID == 34) asm volatile(ASM : "+v"(a[i]) : "v"(b), "s"(smask) : "vcc"); \
+        else if (ID == 37) { a[i] &= 1023u; asm volatile(ASM : "+v"(a[i]) : "v"(b) : "vcc", "memory"); } \
         else asm volatile(ASM : "+v"(a[i]) : "v"(b) : "vcc"); \
     }
                 OPS(X)

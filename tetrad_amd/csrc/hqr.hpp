@@ -65,7 +65,12 @@ tq_bidiag_kernel(const uint32_t *__restrict__ cm, int64_t Q, double *__restrict_
                  uint32_t *__restrict__ nsnps_out, uint32_t *__restrict__ cmats_dbg)
 {
     constexpr int QP = 16;                       // quartets per wave pass (one per quad)
-    __shared__ uint32_t lds[QP * 256];
+    // a quartet's 256 counts sit 260 dwords apart: the 16 quads read the same bin of 16 different quartets in every
+    // ds_read, and with a pitch of 256 all of them hit one bank (SQ_LDS_BANK_CONFLICT 85 % of the LDS-busy cycles);
+    // with 4 dwords of padding quad q is displaced by 4q banks, which is conflict-free for flattenings 0 and 1
+    // (a quad's four lanes read 4 consecutive bins) and 4-way for flattening 2 (bins 4 apart)
+    constexpr int QPITCH = 260;
+    __shared__ uint32_t lds[QP * QPITCH];
     const int lane = threadIdx.x;
     const int quad = lane >> 2;
     const int c = lane & 3;
@@ -78,14 +83,14 @@ tq_bidiag_kernel(const uint32_t *__restrict__ cm, int64_t Q, double *__restrict_
             uint4 *dst = reinterpret_cast<uint4 *>(lds);
 #pragma unroll
             for (int k = 0; k < 16; ++k) {
-                const int idx = lane + WAVE * k;               // 1024 uint4 = 16 quartets x 64
-                const bool ok = (q0 + (idx >> 6)) < Q;
-                dst[idx] = ok ? src[idx] : make_uint4(0, 0, 0, 0);
+                const int idx = lane + WAVE * k;               // 1024 uint4 = 16 quartets x 64: quartet k, piece lane
+                const bool ok = (q0 + k) < Q;
+                dst[k * (QPITCH / 4) + lane] = ok ? src[idx] : make_uint4(0, 0, 0, 0);
             }
         }
         __syncthreads();
         const int64_t myq = q0 + quad;
-        const uint32_t *cmq = lds + 256 * quad;
+        const uint32_t *cmq = lds + QPITCH * quad;
         // resolve_quartets.py:226: number of counted sites = sum of the count tensor
         {
             uint32_t s = 0;
@@ -99,14 +104,27 @@ tq_bidiag_kernel(const uint32_t *__restrict__ cm, int64_t Q, double *__restrict_
 #pragma unroll 1
         for (int t = 0; t < 3; ++t) {
             double a[4][16];                                    // a[s][r] = M_t[r][4s + c]
+            // bin of M_t[r][4s + c], r = 4 rh + rl: 64 rh + RL rl + SS s + CS c with (RL, SS, CS) = (16, 4, 1), (4, 16, 1),
+            // (1, 16, 4) for t = 0, 1, 2 (flat_bin).  t is a runtime (scalar) value, so the three strides are SGPRs: 16
+            // per-lane addresses (one per (rl, s)) and the four rh of each as compile-time LDS offsets -- with flat_bin(t, ..)
+            // evaluated per element every load paid two selects and two adds for its index (6 % of the kernel)
+            {
+                const int RL = t == 0 ? 16 : (t == 1 ? 4 : 1), SS = t == 0 ? 4 : 16, CS = t == 2 ? 4 : 1;
+                const uint32_t *base = cmq + CS * c;
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {
+                for (int s = 0; s < 4; ++s) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const uint32_t v = cmq[flat_bin(t, r, 4 * s + c)];
-                    a[s][r] = (double)v;
-                    if (DEBUG) {
-                        if (cmats_dbg && myq < Q) cmats_dbg[((myq * 3 + t) * 16 + r) * 16 + 4 * s + c] = v;
+                    for (int rl = 0; rl < 4; ++rl) {
+                        const uint32_t *pp = base + RL * rl + SS * s;
+#pragma unroll
+                        for (int rh = 0; rh < 4; ++rh) {
+                            const int r = 4 * rh + rl;
+                            const uint32_t v = pp[64 * rh];
+                            a[s][r] = (double)v;
+                            if (DEBUG) {
+                                if (cmats_dbg && myq < Q) cmats_dbg[((myq * 3 + t) * 16 + r) * 16 + 4 * s + c] = v;
+                            }
+                        }
                     }
                 }
             }
@@ -182,17 +200,20 @@ tq_bidiag_kernel(const uint32_t *__restrict__ cm, int64_t Q, double *__restrict_
                     const double beta = live ? rcp_nr<1>(den) : 0.0;
                     if (c == c1) y[s1] = x0 - alpha;
                     if (writer) dout[16 + K1] = alpha;
-                    double yb[4];                                // beta * y: one multiply per slot instead of one per row
+                    // -beta * y: one multiply per slot instead of one per row, and the sign goes in here so that the
+                    // row update is a plain v_fmac (the two-operand form has no negate modifier: with fma(-tt, y, a)
+                    // the compiler spent a v_xor per value on sign flips, 145 per matrix)
+                    double yb[4];
 #pragma unroll
-                    for (int s = sb; s < 4; ++s) yb[s] = beta * y[s];
+                    for (int s = sb; s < 4; ++s) yb[s] = -beta * y[s];
 #pragma unroll
                     for (int i = K1; i < 16; ++i) {
                         double q = 0.0;
 #pragma unroll
                         for (int s = sb; s < 4; ++s) q = fma(yb[s], a[s][i], q);
-                        const double tt = quad_sum(q);
+                        const double tt = quad_sum(q);           // = -beta * (row i . y)
 #pragma unroll
-                        for (int s = sb; s < 4; ++s) a[s][i] = fma(-tt, y[s], a[s][i]);
+                        for (int s = sb; s < 4; ++s) a[s][i] = fma(tt, y[s], a[s][i]);
                     }
                 } else if constexpr (K == 14) {
                     const double e15 = quad_bcast<3>(a[3][14]);  // column 15 lives in slot 3 of lane 3
@@ -226,10 +247,33 @@ tq_bdsqr_kernel(const double *__restrict__ de, int64_t nmat, double *__restrict_
         const bool live = m < nmat;
         double anorm = 0.0;
         double dv[16], ev[16];
+        // The wave's 64 bidiagonals are one contiguous 16 KiB tile of `de`.  It is read as sixteen fully coalesced
+        // 1 KiB wave accesses (every line of the tile is touched by exactly one instruction; the lane-per-matrix reads
+        // this replaces touched every line with eight, 256 bytes apart per lane, and fetched 1.5x the tile from memory)
+        // into the LDS park in matrix-major order -- 16-byte piece c of matrix mm at piece slot mm*16 + (c ^ (mm & 15)),
+        // so that both this store and the lane-per-matrix read-back below are bank-conflict free -- then every lane
+        // takes its own matrix to registers and the park is rewritten lane-major for the sweeps.
+        {
+            double2 *stage = reinterpret_cast<double2 *>(lds);
+            const double2 *src = reinterpret_cast<const double2 *>(de + wg * WAVE * 32);
+            const int64_t pieces = (nmat - wg * WAVE) * 16;                 // valid 16-byte pieces from the tile's start
+#pragma unroll
+            for (int it = 0; it < 16; ++it) {
+                const int p = it * WAVE + lane, mm = p >> 4, c = p & 15;
+                stage[mm * 16 + (c ^ (mm & 15))] = p < pieces ? src[p] : make_double2(0.0, 0.0);
+            }
+            __syncthreads();
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const double2 v = stage[lane * 16 + (c ^ (lane & 15))];
+                const double2 u = stage[lane * 16 + ((c + 8) ^ (lane & 15))];
+                dv[2 * c] = v.x; dv[2 * c + 1] = v.y;
+                ev[2 * c] = u.x; ev[2 * c + 1] = u.y;
+            }
+            __syncthreads();
+        }
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-            dv[i] = live ? de[m * 32 + i] : 0.0;
-            ev[i] = live ? de[m * 32 + 16 + i] : 0.0;
             W_(i) = dv[i];
             E_(i) = ev[i];
             anorm = fmax(anorm, fabs(dv[i]) + fabs(ev[i]));
@@ -359,14 +403,30 @@ tq_bdsqr_kernel(const double *__restrict__ de, int64_t nmat, double *__restrict_
             }
             if (lane == 0) atomicAdd(&stats[2], 64ull * wi);
         }
-        if (live) {
+        // results: 16 values per matrix = 8 KiB per wave, staged matrix-major through the park (same piece swizzle)
+        // and written as eight coalesced 1 KiB wave accesses
+        {
+            double out[16];
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 // a matrix that hit the sweep cap hands its values over with the sign bit set (also on
                 // zeros): tq_score_kernel turns that into TQ_FLAG_NO_CONVERGENCE (numpy raises LinAlgError)
                 const double v = fabs(W_(i));
-                sv[m * 16 + i] = noconv ? -v : v;
+                out[i] = noconv ? -v : v;
             }
+            __syncthreads();
+            double2 *stage = reinterpret_cast<double2 *>(lds);
+#pragma unroll
+            for (int c = 0; c < 8; ++c) stage[lane * 8 + (c ^ (lane & 7))] = make_double2(out[2 * c], out[2 * c + 1]);
+            __syncthreads();
+            double2 *dst = reinterpret_cast<double2 *>(sv + wg * WAVE * 16);
+            const int64_t pieces = (nmat - wg * WAVE) * 8;
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int p = it * WAVE + lane, mm = p >> 3, c = p & 7;
+                if (p < pieces) dst[p] = stage[mm * 8 + (c ^ (mm & 7))];
+            }
+            __syncthreads();
         }
     }
 }

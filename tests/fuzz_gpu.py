@@ -1,7 +1,8 @@
 """Randomised GPU-vs-oracle comparison over shapes, sparsity, locus structure, batch sizes and options.
 Usage: python tests/fuzz_gpu.py [seconds] [seed]   (prints one line per case, exits 1 on the first mismatch)"""
 import sys, time
-sys.path.insert(0, '/root/repo')
+from pathlib import Path
+sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
 import numpy as np
 from tetrad_amd import synth
 from tetrad_amd.engine import QuartetEngine

@@ -226,6 +226,30 @@ def test_kernel_level_mirrors(case):
         np.testing.assert_array_equal(RQ.full_chunk_to_matrices(seqs, tmpmap[:, 0], mask), g["full_cmats"][qi])
 
 
+def test_kernel_level_mirrors_honour_an_arbitrary_caller_mask(oracle):
+    """The reference's count kernels count EVERY site their caller's mask leaves open (resolve_quartets.py:59-64,
+    :89-95), invariant sites included -- only the worker's own mask (:216-218) always closes those.  A mask that is
+    not the worker's: missing sites closed (the reference would index out of bounds on them), a random third of the
+    others closed, invariant sites left open.  Against the oracle's restatement of the two kernels."""
+    from tetrad_amd import resolve_quartets as RQ
+    g = load_golden("tree_T12_S2000")
+    tmparr, tmpmap = g["tmparr"], g["tmpmap"]
+    rng = np.random.default_rng(3)
+    for qi in (0, 200, 494):
+        seqs = tmparr[g["quartets"][qi], :]
+        missing = (seqs >= 78).any(axis=0)
+        mask = (missing | (rng.random(seqs.shape[1]) < 0.33)).astype(np.int64)
+        invariant_open = ((seqs == seqs[0]).all(axis=0) & (mask == 0)).sum()
+        assert invariant_open > 100                                   # the case the worker's mask never produces
+        for sub, fn, ofn in ((True, RQ.subsample_chunk_to_matrices, oracle.subsample_chunk_to_matrices),
+                             (False, RQ.full_chunk_to_matrices, oracle.full_chunk_to_matrices)):
+            want = ofn(seqs, tmpmap[:, 0], mask)
+            got = fn(seqs, tmpmap[:, 0], mask)
+            np.testing.assert_array_equal(got, want)
+            if not sub:
+                assert got[0].sum() == (mask == 0).sum()              # every open site counted once
+
+
 def test_end_to_end_engine_rows_to_supertree(engine):
     """Data simulated on a known tree -> engine (all quartets) -> wQMC lines -> clean-room QMC: the generating tree
     comes back, for 16 taxa (c1) and for 40 taxa with a sampled quartet set."""

@@ -51,6 +51,62 @@ def test_device_sampler_draws_distinct_uniform_quartets():
             eng.sample_quartets_dev(1, N + 1, d_q2.data_ptr(), 0)
 
 
+def test_device_sampler_matches_the_distribution_of_choice_without_replacement():
+    """The opt-in device sampler is documented as distribution-equal to `rng.choice(C(T,4), Q, replace=False)`
+    (combinations.py:109-114), not stream-equal.  Chi-square tests at the c3 shape (128 taxa, 1e5 of 10.7e6):
+    ranks over 256 equal bins, first-taxon frequencies against their exact law C(T-a-1,3)/C(T,4), last-taxon
+    frequencies likewise, for related seeds (s, s+1, s with a high bit flipped: the round keys come from a
+    splitmix64 chain, so related seeds must give unrelated samples), and against NumPy's own sampler as a
+    two-sample check."""
+    import torch
+    from math import comb
+    from tetrad_amd import synth
+    from tetrad_amd.engine import QuartetEngine
+    T, Q = 128, 100_000
+    N = comb(T, 4)
+    tmparr, tmpmap = synth.simulate_tmparr(T, 64, seed=1)
+    dev = torch.device("cuda:0")
+    first_p = np.array([comb(T - a - 1, 3) for a in range(T)], float) / N
+    last_p = np.array([comb(d, 3) for d in range(T)], float) / N
+    keep_f, keep_l = first_p * Q >= 20, last_p * Q >= 20            # pool the thin tails out of the statistic
+
+    def chi2(counts, p, keep):
+        e = p[keep] * Q
+        return float((((counts[keep] - e) ** 2) / e).sum()), int(keep.sum()) - 1
+
+    def ok(stat, dof):                                              # within 5 sigma of a chi-square's mean
+        return abs(stat - dof) < 5 * np.sqrt(2 * dof)
+
+    samples = {}
+    with QuartetEngine(0) as eng:
+        eng.set_data(tmparr, tmpmap)
+        for seed in (7, 8, 7 ^ (1 << 40), 0, 2**63 - 1):
+            d_q = torch.empty((Q, 4), dtype=torch.int32, device=dev)
+            d_r = torch.empty(Q, dtype=torch.int64, device=dev)
+            eng.sample_quartets_dev(seed, Q, d_q.data_ptr(), d_r.data_ptr())
+            torch.cuda.synchronize()
+            r, q = d_r.cpu().numpy(), d_q.cpu().numpy()
+            assert len(np.unique(r)) == Q
+            bins = np.bincount((r // (N // 256 + 1)).astype(int), minlength=256)
+            width = np.diff(np.minimum(np.arange(257) * (N // 256 + 1), N)).astype(float)
+            stat = float((((bins - Q * width / N) ** 2) / (Q * width / N)).sum())
+            assert ok(stat, 255), ("rank bins", seed, stat)
+            s1, d1 = chi2(np.bincount(q[:, 0], minlength=T), first_p, keep_f)
+            s2, d2 = chi2(np.bincount(q[:, 3], minlength=T), last_p, keep_l)
+            assert ok(s1, d1) and ok(s2, d2), ("taxon frequencies", seed, s1, d1, s2, d2)
+            samples[seed] = r
+    # related seeds: overlaps like independent samples (expected Q*Q/N = 937, sd ~ 30)
+    for a, b in ((7, 8), (7, 7 ^ (1 << 40)), (0, 2**63 - 1)):
+        inter = len(np.intersect1d(samples[a], samples[b]))
+        assert abs(inter - Q * Q / N) < 6 * np.sqrt(Q * Q / N), (a, b, inter)
+    # two-sample check against NumPy's sampler: the same bin statistic between the two samples
+    ref = np.random.default_rng(5).choice(N, size=Q, replace=False)
+    b1 = np.bincount((samples[7] // (N // 256 + 1)).astype(int), minlength=256).astype(float)
+    b2 = np.bincount((ref // (N // 256 + 1)).astype(int), minlength=256).astype(float)
+    stat = float((((b1 - b2) ** 2) / (b1 + b2)).sum())
+    assert ok(stat, 255), ("two-sample", stat)
+
+
 @pytest.mark.parametrize("sampler", ["host", "device"])
 def test_replicate_runner_equals_step_by_step(oracle, sampler):
     """Four replicates through the pipelined runner == the same draws applied step by step with a second

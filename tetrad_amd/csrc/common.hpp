@@ -23,6 +23,8 @@ struct DevData {
     int64_t W;          // plane records per row (Sp/32)
     int32_t T;
     int32_t ntiles;     // Sp / TILE
+    uint32_t inv;       // 0, or ~0 with option "count_invariant": sites where the four bases are equal are counted too (the
+                        // kernel-level mirrors of resolve_quartets.py:42-104 honour a caller's mask exactly; one-wave kernel only)
 };
 
 // Byte offset of site s inside a row.  A 2048-site step is stored as two 1 KiB panels: panel 0

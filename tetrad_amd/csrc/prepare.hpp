@@ -115,14 +115,36 @@ __device__ __forceinline__ uint32_t feistel_round(uint32_t x, uint32_t key)
     return x;
 }
 
-__device__ __forceinline__ uint64_t feistel_permute(uint64_t v, int half_bits, uint64_t seed)
+// six independent 32-bit round keys from the 64-bit seed: a splitmix64 chain (Steele, Lea & Flood 2014), one output
+// per round (shifted bytes of one seed plus a round constant -- the first version -- made rounds r and r+4 differ by a
+// constant only)
+struct FeistelKeys {
+    uint32_t k[6];
+};
+
+__device__ __forceinline__ FeistelKeys feistel_keys(uint64_t seed)
+{
+    FeistelKeys ks;
+    uint64_t x = seed;
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+        x += 0x9E3779B97F4A7C15ull;
+        uint64_t z = x;
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        z ^= z >> 31;
+        ks.k[r] = (uint32_t)(z >> 16);
+    }
+    return ks;
+}
+
+__device__ __forceinline__ uint64_t feistel_permute(uint64_t v, int half_bits, const FeistelKeys &ks)
 {
     const uint32_t mask = half_bits >= 32 ? 0xFFFFFFFFu : ((1u << half_bits) - 1u);
     uint32_t L = (uint32_t)(v >> half_bits) & mask, R = (uint32_t)v & mask;
 #pragma unroll
     for (int r = 0; r < 6; ++r) {
-        const uint32_t key = (uint32_t)(seed >> (8 * (r & 3))) + 0x9E3779B9u * (uint32_t)(r + 1) + (uint32_t)(seed >> 32);
-        const uint32_t t = L ^ (feistel_round(R, key) & mask);
+        const uint32_t t = L ^ (feistel_round(R, ks.k[r]) & mask);
         L = R;
         R = t;
     }
@@ -134,9 +156,10 @@ __global__ void tq_sample_kernel(uint64_t seed, uint64_t N, int half_bits, int64
 {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= Q) return;
+    const FeistelKeys ks = feistel_keys(seed);
     uint64_t v = (uint64_t)i;
     do {                                    // expected < 4 rounds: 2^(2*half_bits) < 4N
-        v = feistel_permute(v, half_bits, seed);
+        v = feistel_permute(v, half_bits, ks);
     } while (v >= N);
     if (ranks_out) ranks_out[i] = v;
     uint64_t index = v;

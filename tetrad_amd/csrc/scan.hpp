@@ -80,11 +80,11 @@ __device__ __forceinline__ uint32_t count_from_candidates(uint32_t U, uint32_t B
 
 template <bool SUB>
 __device__ __forceinline__ uint32_t count_mask(const uint4 &pa, const uint4 &pb, const uint4 &pc, const uint4 &pd,
-                                               int lane, uint32_t &tile_carry)
+                                               int lane, uint32_t &tile_carry, uint32_t inv = 0u)
 {
     const uint32_t M = pa.x | pb.x | pc.x | pd.x;
     const uint32_t V = (pa.y ^ pb.y) | (pa.z ^ pb.z) | (pa.y ^ pc.y) | (pa.z ^ pc.z) |
-                       (pa.y ^ pd.y) | (pa.z ^ pd.z);
+                       (pa.y ^ pd.y) | (pa.z ^ pd.z) | inv;
     return count_from_candidates<SUB>(V & ~M, pa.w, lane, tile_carry);
 }
 
@@ -271,9 +271,9 @@ __device__ __forceinline__ uint32_t pat4(uint32_t a, uint32_t b, uint32_t c, uin
 
 template <int NREP, bool SUB, int METHOD>
 __device__ __forceinline__ void process_tile(const TileRegs &t, int lane, uint32_t &tile_carry, uint32_t *hrep,
-                                             uint8_t *park)
+                                             uint8_t *park, uint32_t inv)
 {
-    const uint32_t C = count_mask<SUB>(t.pa, t.pb, t.pc, t.pd, lane, tile_carry);
+    const uint32_t C = count_mask<SUB>(t.pa, t.pb, t.pc, t.pd, lane, tile_carry, inv);
     uint32_t pat[8];
     pat[0] = pat4(t.a0.x, t.b0.x, t.c0.x, t.d0.x);
     pat[1] = pat4(t.a0.y, t.b0.y, t.c0.y, t.d0.y);
@@ -302,12 +302,12 @@ __device__ __forceinline__ void scan_quartet(const DevData &d, const uint32_t (&
     for (int t = 0; t < d.ntiles; t += 2) {
         load_tile(B, d, q, min(t + 1, last), lane);
         __builtin_amdgcn_sched_barrier(0);
-        process_tile<NREP, SUB, METHOD>(A, lane, tile_carry, hrep, park);
+        process_tile<NREP, SUB, METHOD>(A, lane, tile_carry, hrep, park, d.inv);
         __builtin_amdgcn_sched_barrier(0);
         if (t + 1 >= d.ntiles) break;
         load_tile(A, d, q, min(t + 2, last), lane);
         __builtin_amdgcn_sched_barrier(0);
-        process_tile<NREP, SUB, METHOD>(B, lane, tile_carry, hrep, park);
+        process_tile<NREP, SUB, METHOD>(B, lane, tile_carry, hrep, park, d.inv);
         __builtin_amdgcn_sched_barrier(0);
     }
 }

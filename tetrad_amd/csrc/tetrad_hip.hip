@@ -119,6 +119,9 @@ struct tq_ctx {
                                          // lane-slots issued (64 x wave iterations), sweeps} summed over the launches
     int scan_wg = 4;                // waves per workgroup of the cooperative scan kernel (1 = one wave per quartet)
     int xcd_remap = 1;              // 1: scan workgroups of one XCD take a contiguous part of the sorted order
+    int count_invariant = 0;        // 1: invariant sites (all four bases equal, none missing) are counted as well -- what the reference's
+                                    // count kernels do when their caller's mask leaves such a site open (resolve_quartets.py:59-64);
+                                    // the worker itself always masks them (:218).  One-wave-per-quartet kernel only.
     int park_t = 1;                 // 1 (default): transposed pattern park of the set-bit walk (conflict-free byte reads at the price of
                                     // 2 more VALU per counted site: c3 6.79 -> 6.42 ms); 0: lane-contiguous park (A/B)
     int share_c = 0;                // 1: scan kernel variant that also shares row c inside a workgroup (scan.hpp: SHC;
@@ -417,6 +420,7 @@ DevData dev_data(const tq_ctx *ctx)
     d.W = ctx->W;
     d.T = (int32_t)ctx->T;
     d.ntiles = (int32_t)(ctx->Sp / TILE);
+    d.inv = ctx->count_invariant ? 0xFFFFFFFFu : 0u;
     return d;
 }
 
@@ -476,7 +480,7 @@ int launch_scan_wg(tq_ctx *ctx, const uint32_t *dq, const uint32_t *order, int64
 int launch_scan_n(tq_ctx *ctx, const uint32_t *dq, const uint32_t *order, int64_t Q, int subsample,
                   hipStream_t stream)
 {
-    if (ctx->scan_wg >= 2 && Q >= 64 && (uint64_t)ctx->T * (uint64_t)ctx->Sp < 0xFFFF0000ull) {
+    if (ctx->scan_wg >= 2 && Q >= 64 && !ctx->count_invariant && (uint64_t)ctx->T * (uint64_t)ctx->Sp < 0xFFFF0000ull) {
         const int m = ctx->scan_method < 0 ? (subsample ? 1 : 0) : ctx->scan_method;
 #define TQ_WG_CASE(NW)                                                                                   \
     if (ctx->scan_wg == NW) {                                                                            \
@@ -1306,6 +1310,10 @@ int tq_set_option(tq_ctx *ctx, const char *name, int64_t value)
     }
     if (!strcmp(name, "xcd_remap")) {
         ctx->xcd_remap = value != 0;
+        return TQ_OK;
+    }
+    if (!strcmp(name, "count_invariant")) {
+        ctx->count_invariant = value != 0;
         return TQ_OK;
     }
     if (!strcmp(name, "park_t")) {

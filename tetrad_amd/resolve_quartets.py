@@ -121,9 +121,12 @@ def load_database(database, with_token: bool = False):
 def _chunk_to_matrices(seqs, locus, mask, subsample: bool, device_id: int = 0):
     """Kernel-level interface: seqs u8[4,S], locus u32[S], mask[S] -> u32[3,16,16].
 
-    The reference computes ``mask`` from ``seqs`` (:216-218) before calling the
-    kernel; the device scan derives the same mask itself, so a caller-supplied
-    mask is folded into the data by marking masked sites missing."""
+    The caller's ``mask`` is honoured exactly as the reference's count kernels honour it
+    (resolve_quartets.py:59-64, :89-95): every site it leaves open is a candidate -- invariant sites
+    included (engine option ``count_invariant``: the worker's own mask, :216-218, never leaves one open,
+    but a caller's may) -- and every site it closes is skipped, whatever the bases there.  One
+    difference, on input the reference does not define: a site left open whose bases are not all in
+    0..3 (a missing 78 would index outside the 16x16 matrix there) is skipped here."""
     seqs = np.ascontiguousarray(seqs, dtype=np.uint8)
     if seqs.ndim != 2 or seqs.shape[0] != 4:
         raise ValueError("seqs must be u8[4,S]")
@@ -131,6 +134,7 @@ def _chunk_to_matrices(seqs, locus, mask, subsample: bool, device_id: int = 0):
     seqs[:, np.asarray(mask) != 0] = 78
     locus = np.ascontiguousarray(locus, dtype=np.uint32)
     with QuartetEngine(device_id) as eng:
+        eng.set_option("count_invariant", 1)
         eng.set_data(seqs, locus)
         _, _, _, dbg = eng.resolve(np.array([[0, 1, 2, 3]], np.uint32), subsample, debug=True)
     return dbg["cmats"][0]

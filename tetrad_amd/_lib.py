@@ -89,7 +89,10 @@ def load() -> ctypes.CDLL:
         import torch  # noqa: F401
     except ImportError:  # torch is plumbing, not a requirement of the host-buffer API
         pass
-    lib = ctypes.CDLL(str(LIB_PATH))
+    # developer knob for A/B runs of alternative builds of the same source (tools/ab/*.so): never a fallback --
+    # a path that does not exist fails exactly like a missing library
+    alt = os.environ.get("TQ_LIB_PATH")
+    lib = ctypes.CDLL(alt if alt else str(LIB_PATH))
     c = ctypes
     vp, i64, i32 = c.c_void_p, c.c_int64, c.c_int
     lib.tq_create.argtypes = [c.POINTER(vp), i32]

@@ -126,6 +126,22 @@ __device__ __forceinline__ uint32_t lds_offset(const void *p) { return (uint32_t
 // (stride 36 bytes) pays 2.5 extra LDS cycles per read instruction on c3 (rocprofv3: SQ_LDS_BANK_CONFLICT of the
 // walk without atomics) -- at the price of two more vector instructions per counted site for the address
 // lanebase + (i >> 2) * 256 + (i & 3) = (lanebase + i) + (i >> 2) * 252.
+// Wave priority during the walk (s_setprio): a wave in its walk is a chain of LDS round trips, a wave outside it issues
+// vector instructions back to back; raised priority for the walking waves keeps the LDS pipe fed (c3 scan 5.99 -> 5.90 ms;
+// the opposite setting 6.05 ms; A/B builds with -DTQ_WALK_PRIO=0|1|2 through TQ_LIB_PATH).
+#ifndef TQ_WALK_PRIO
+#define TQ_WALK_PRIO 1
+#endif
+#if TQ_WALK_PRIO == 1
+#define TQ_WALK_PRIO_ON "s_setprio 2\n\t"
+#define TQ_WALK_PRIO_OFF "s_setprio 0\n\t"
+#elif TQ_WALK_PRIO == 2
+#define TQ_WALK_PRIO_ON "s_setprio 0\n\t"
+#define TQ_WALK_PRIO_OFF "s_setprio 2\n\t"
+#else
+#define TQ_WALK_PRIO_ON
+#define TQ_WALK_PRIO_OFF
+#endif
 template <bool ATOMICS = true, bool TRANSPOSED = false>
 __device__ __forceinline__ void walk_set_bits(uint32_t c, uint32_t park_off, uint32_t hist_off)
 {
@@ -135,6 +151,7 @@ __device__ __forceinline__ void walk_set_bits(uint32_t c, uint32_t park_off, uin
         uint32_t one = 1u, k252 = 252u;
         asm volatile(
             "s_mov_b64 %[save], exec\n\t"
+            TQ_WALK_PRIO_ON
             "v_add_co_u32_e32 %[t], vcc, -1, %[c]\n\t"
             "s_and_b64 exec, exec, vcc\n\t"
             "s_cbranch_execz 1f\n"
@@ -152,6 +169,7 @@ __device__ __forceinline__ void walk_set_bits(uint32_t c, uint32_t park_off, uin
             "s_and_b64 exec, exec, vcc\n\t"
             "s_cbranch_execnz 0b\n"
             "1:\n\t"
+            TQ_WALK_PRIO_OFF
             "s_mov_b64 exec, %[save]"
             : [c] "+v"(c), [t] "=&v"(t), [i] "=&v"(i), [j] "=&v"(j), [b] "=&v"(b), [save] "=&s"(save)
             : [park] "v"(park_off), [hist] "s"(hist_off), [one] "v"(one), [k252] "s"(k252)
@@ -447,7 +465,7 @@ tq_scan_wg_kernel(DevData d, const uint32_t *__restrict__ quartets, const uint32
                   uint32_t *__restrict__ cm, int64_t xcd_chunk)
 {
     static_assert(NW >= 1 && NW <= 16, "waves per workgroup");
-    static_assert(!SHC || NW >= 4, "the row-c job needs a fourth wave");
+    static_assert(!SHC || NW >= 3, "the row-c job needs a third wave");
     __shared__ uint4 shared_ab[2][SHC ? SHARED_SLOTS_C : SHARED_SLOTS];
     // (two copies of the wave's histogram, odd and even lanes apart, were measured: SQ_LDS_ADDR_CONFLICT 563M -> 350M
     // per dispatch, SQ_LDS_BANK_CONFLICT and the LDS-busy cycles unchanged to the digit, 6.42 -> 6.58 ms with the lower
@@ -470,14 +488,18 @@ tq_scan_wg_kernel(DevData d, const uint32_t *__restrict__ quartets, const uint32
     const uint8_t *nib = d.nib;
     const uint8_t *planes = reinterpret_cast<const uint8_t *>(d.planes);
     const uint8_t *planes3 = reinterpret_cast<const uint8_t *>(d.planes3);
-    const uint8_t *runbeg = reinterpret_cast<const uint8_t *>(d.runbeg);
     const uint32_t pitch = (uint32_t)d.pitch, npitch = pitch / 2, wpitch = (uint32_t)d.W * 16u,
                    w3pitch = (uint32_t)d.W * 12u;
     // cooperative jobs per step: 0,1 = nibble codes of rows a and b for sites 0-15 / 16-31
     // of every lane -> abp panels 0,1; 2 = plane records of a and b (+ run-begin bits) -> r1, B.
-    // Wave w takes the jobs j with j % NW == w.
-    // With SHC: 3 = nibble codes and plane record of the block's common row c.
-    constexpr int NJOB = SHC ? 4 : 3, JPW = (NJOB + NW - 1) / NW;        // jobs per wave
+    // Wave w takes the jobs j with j % NW == w.  A vector load costs the CU's texture-address path ~18 cycles per
+    // wave-instruction whatever its width (tools/probe_ta.hip) and that path is what bounds the load side of this
+    // kernel (TA_TA_BUSY 95 % of the CU-busy cycles with the histogram taken out, profiles/r03_scan), so the shared
+    // part is fetched with the FEWEST instructions: job 0 = nibble codes of a and of b, one 16-byte load each (it was
+    // four 8-byte loads in two jobs); job 1 = the 16-byte plane records {miss, p0, p1, run-begin} of a and b (it was two
+    // 12-byte records plus a run-begin load).  9 -> 4 loads per workgroup-step, 6.25 -> 5 per wave-step.
+    // With SHC: job 2 = nibble codes and plane record of the block's common row c.
+    constexpr int NJOB = SHC ? 3 : 2, JPW = (NJOB + NW - 1) / NW;        // jobs per wave
     __syncthreads();
 
     const int64_t nslot = xcd_chunk > 0 ? 8 * xcd_chunk : nblk;
@@ -537,38 +559,32 @@ tq_scan_wg_kernel(DevData d, const uint32_t *__restrict__ quartets, const uint32
         // cooperative loads of this thread (values are passed and returned by value: address-taken
         // locals end up in scratch memory, which costs a memory round trip per step)
         auto job_of = [=](int i) { return w + i * NW; };                       // wave-uniform
-        auto ld8 = [=](const uint8_t *base, uint32_t off) -> uint2 { return *reinterpret_cast<const uint2 *>(base + off); };
         auto fetch_x = [=](int job, int tile) -> uint4 {
-            if (job < 2) {                                   // 8 nibble bytes (16 sites) of a and of b
-                const uint32_t o = (uint32_t)lane * 16u + (uint32_t)job * 8u + (uint32_t)tile * (TILE / 2);
-                const uint2 xa = ld8(nib, la * npitch + o), xb = ld8(nib, lb * npitch + o);
-                return make_uint4(xa.x, xa.y, xb.x, xb.y);
-            }
-            if (job == 2) {
-                uint4 r = ld12(planes3, la * w3pitch + (uint32_t)lane * 12u + (uint32_t)tile * (WAVE * 12));
-                r.w = *reinterpret_cast<const uint32_t *>(runbeg + (uint32_t)lane * 4u + (uint32_t)tile * (WAVE * 4));
-                return r;
-            }
-            if (SHC && job == 3 && shc) return ld16(nib, lc * npitch + (uint32_t)lane * 16u + (uint32_t)tile * (TILE / 2));
+            if (job == 0) return ld16(nib, la * npitch + (uint32_t)lane * 16u + (uint32_t)tile * (TILE / 2));
+            if (job == 1) return ld16(planes, la * wpitch + (uint32_t)lane * 16u + (uint32_t)tile * (WAVE * 16));
+            if (SHC && job == 2 && shc) return ld16(nib, lc * npitch + (uint32_t)lane * 16u + (uint32_t)tile * (TILE / 2));
             return make_uint4(0, 0, 0, 0);
         };
         auto fetch_y = [=](int job, int tile) -> uint4 {
-            if (job == 2) return ld12(planes3, lb * w3pitch + (uint32_t)lane * 12u + (uint32_t)tile * (WAVE * 12));
-            if (SHC && job == 3 && shc) return ld12(planes3, lc * w3pitch + (uint32_t)lane * 12u + (uint32_t)tile * (WAVE * 12));
+            if (job == 0) return ld16(nib, lb * npitch + (uint32_t)lane * 16u + (uint32_t)tile * (TILE / 2));
+            if (job == 1) return ld16(planes, lb * wpitch + (uint32_t)lane * 16u + (uint32_t)tile * (WAVE * 16));
+            if (SHC && job == 2 && shc) return ld12(planes3, lc * w3pitch + (uint32_t)lane * 12u + (uint32_t)tile * (WAVE * 12));
             return make_uint4(0, 0, 0, 0);
         };
         // what goes into the LDS image of one step (uint4 slots): abp panels 0-63 / 64-127 =
         // ((a<<2)+b)<<4 per site byte; r1 128-191 = {p0a, p1a, Ma|Mb, (p0a^p0b)|(p1a^p1b)};
         // run-begin words 192-207 (64 dwords)
         auto publish = [=](uint4 *buf, int job, uint4 x, uint4 y) {
-            if (job < 2) {
+            if (job == 0) {
                 // a*4+b per nibble: codes are 0..3, so the packed word can be shifted as a whole
-                const uint32_t h = 0xF0F0F0F0u, s0 = (x.x << 2) + x.z, s1 = (x.y << 2) + x.w;
-                buf[job * 64 + lane] = make_uint4((s0 << 4) & h, s0 & h, (s1 << 4) & h, s1 & h);
-            } else if (job == 2) {
+                const uint32_t h = 0xF0F0F0F0u;
+                const uint32_t s0 = (x.x << 2) + y.x, s1 = (x.y << 2) + y.y, s2 = (x.z << 2) + y.z, s3 = (x.w << 2) + y.w;
+                buf[lane] = make_uint4((s0 << 4) & h, s0 & h, (s1 << 4) & h, s1 & h);           // sites 0-15 of the lane
+                buf[64 + lane] = make_uint4((s2 << 4) & h, s2 & h, (s3 << 4) & h, s3 & h);      // sites 16-31
+            } else if (job == 1) {                           // x, y = {miss, p0, p1, run-begin} of a, of b
                 buf[128 + lane] = make_uint4(x.y, x.z, x.x | y.x, (x.y ^ y.y) | (x.z ^ y.z));
                 reinterpret_cast<uint32_t *>(buf + 192)[lane] = x.w;
-            } else if (SHC && job == 3 && shc) {
+            } else if (SHC && job == 2 && shc) {
                 buf[SHARED_SLOTS + lane] = x;                  // nibble codes of row c
                 buf[SHARED_SLOTS + 64 + lane] = y;             // its plane record {miss, p0, p1, 0}
             }

@@ -498,6 +498,9 @@ int launch_scan_n(tq_ctx *ctx, const uint32_t *dq, const uint32_t *order, int64_
         if (ctx->scan_wg == 4 && ctx->park_t && m == 1 && !ctx->share_c)
             return subsample ? launch_scan_wg<true, 1, 4, false, true>(ctx, dq, order, Q, stream)
                              : launch_scan_wg<false, 1, 4, false, true>(ctx, dq, order, Q, stream);
+        if ((ctx->scan_wg == 8 || ctx->scan_wg == 6) && ctx->park_t && m == 1 && subsample && !ctx->share_c)
+            return ctx->scan_wg == 8 ? launch_scan_wg<true, 1, 8, false, true>(ctx, dq, order, Q, stream)
+                                     : launch_scan_wg<true, 1, 6, false, true>(ctx, dq, order, Q, stream);
         if (ctx->scan_wg == 4 && ctx->share_c && m <= 1) {
             if (subsample)
                 return m ? launch_scan_wg<true, 1, 4, true>(ctx, dq, order, Q, stream)

@@ -226,6 +226,33 @@ def test_kernel_level_mirrors(case):
         np.testing.assert_array_equal(RQ.full_chunk_to_matrices(seqs, tmpmap[:, 0], mask), g["full_cmats"][qi])
 
 
+@pytest.mark.parametrize("cfg,nq", [("c3", 40_000), ("c2", 60_000)])
+def test_scan_kernel_variants_agree_on_sorted_batches(cfg, nq):
+    """Batches large enough to be sorted by (a,b,c) and scanned by the cooperative kernel with shared rows
+    (>= 32 768 quartets): every alternative form of the scan kernel -- lane-contiguous pattern park, two quartets per
+    wavefront, row c through LDS, 8-wave workgroups, EXEC-masked counting in subsample mode and the walk in full
+    mode -- must give bitwise the rows of the default form, in both modes."""
+    from tetrad_amd import synth
+    from tetrad_amd.engine import QuartetEngine
+    T, S, _ = synth.CONFIGS[cfg]
+    tmparr, tmpmap = synth.simulate_tmparr(T, S, synth.CONFIG_SEEDS[cfg])
+    q = synth.all_quartets(T)[:nq] if cfg == "c2" else synth.random_quartets(T, nq, seed=5)
+    defaults = {"park_t": 1, "scan_pair": 0, "share_c": 0, "scan_wg": 0, "scan_method": -1}
+    with QuartetEngine(0) as eng:
+        eng.set_data(tmparr, tmpmap)
+        for sub in (True, False):
+            base = eng.resolve(q, sub)
+            for opts in ({"park_t": 0}, {"scan_pair": 1}, {"scan_pair": 1, "scan_method": 1 - int(sub)}, {"share_c": 1},
+                         {"scan_wg": 8}, {"scan_method": 1 - int(sub)}):
+                for k, v in opts.items():
+                    eng.set_option(k, v)
+                got = eng.resolve(q, sub)
+                for k in opts:
+                    eng.set_option(k, defaults[k])
+                for a, b in zip(base, got):
+                    np.testing.assert_array_equal(a, b, err_msg=f"{opts} sub={sub}")
+
+
 def test_kernel_level_mirrors_honour_an_arbitrary_caller_mask(oracle):
     """The reference's count kernels count EVERY site their caller's mask leaves open (resolve_quartets.py:59-64,
     :89-95), invariant sites included -- only the worker's own mask (:216-218) always closes those.  A mask that is

@@ -319,12 +319,14 @@ def test_pipeline_options_do_not_change_results(engine):
     q = np.tile(g["quartets"], (3, 1))
     base = engine.resolve(q, True)
     defaults = {"scan_wg": 0, "xcd_remap": 1, "order": 1, "scan_method": -1, "waves_per_cu": 0, "svd_wpc": 0,
-                "batch": 0, "svd_chunk": 0, "share_c": 0, "svd_streams": 0}
+                "batch": 0, "svd_chunk": 0, "share_c": 0, "svd_streams": 0, "park_t": 1, "scan_pair": 0}
     try:
         for opts in ({"scan_wg": 1}, {"scan_wg": 2}, {"scan_wg": 8}, {"scan_wg": 16}, {"xcd_remap": 0},
                      {"waves_per_cu": 12}, {"svd_wpc": 8}, {"order": 0}, {"batch": 700}, {"scan_method": 0},
                      {"svd_chunk": 1000}, {"svd_chunk": 64, "batch": 999}, {"svd_chunk": 1}, {"share_c": 1},
-                     {"share_c": 1, "scan_method": 0}, {"svd_streams": 1, "svd_chunk": 500}):
+                     {"share_c": 1, "scan_method": 0}, {"svd_streams": 1, "svd_chunk": 500}, {"park_t": 0},
+                     {"park_t": 0, "scan_method": 1}, {"scan_method": 1}, {"scan_pair": 1}, {"scan_pair": 1, "scan_method": 0},
+                     {"scan_pair": 1, "order": 0, "batch": 701}):
             for k, v in opts.items():
                 engine.set_option(k, v)
             if opts.get("svd_chunk") == 1:

@@ -694,3 +694,230 @@ tq_scan_wg_kernel(DevData d, const uint32_t *__restrict__ quartets, const uint32
         __syncthreads();
     }
 }
+
+// ------------------------------------------------------------------------------------
+// kernel 1, two quartets per wavefront ("pair" form of the cooperative kernel).
+// The load side of tq_scan_wg_kernel is bound by the number of vector load instructions a CU can issue (~18 cycles
+// of its texture-address path each, whatever the width): 4 per wave-step for the wave's own rows c, d + 4 per
+// workgroup-step for the shared rows a, b = 5 per quartet-step.  Here a wave owns TWO neighbours of the sorted order
+// and works through them one after the other inside every 2048-site step: the shared image is fetched once per EIGHT
+// quartets (NW = 4 waves) and read from LDS once per two, and when the two quartets have the same third taxon -- the
+// rule in lexicographic enumerations (combinations.py:40-55), 60 % of the pairs of a sorted 1e6-of-10.7e6 sample --
+// row c is loaded once: 6 (or 8) own loads per wave-step for two quartets, 3.5 - 4.5 loads per quartet-step.
+// Everything else (count mask, subsample carry per quartet, pattern build, transposed park, set-bit walk into the
+// quartet's own histogram) is the code of the one-quartet form.  METHOD 0 / 1 as there.
+// ------------------------------------------------------------------------------------
+// MEASURED SLOWER, off by default (option "scan_pair", parity-tested; profiles/r03_scan/pair_kernel_ab.txt): c3 5.85 -> 7.34 ms,
+// c2 1.57 -> 1.90 ms.  The state of two quartets costs 109 VGPRs = 4 waves per SIMD (61 = 8 in the one-quartet form; forced to
+// 80 registers the compiler spills 53 of them, i.e. more vector memory instructions), so a CU holds the same 32 quartets in
+// half as many, twice as long instruction streams: the 22 - 30 % fewer loads do not make up for the latency no longer hidden.
+template <bool SUB, int METHOD, int NW>
+__global__ void __launch_bounds__(NW *WAVE)
+tq_scan_wg2_kernel(DevData d, const uint32_t *__restrict__ quartets, const uint32_t *__restrict__ order, int64_t Q,
+                   uint32_t *__restrict__ cm, int64_t xcd_chunk)
+{
+    static_assert(NW >= 2 && NW <= 8, "waves per workgroup");
+    static_assert(METHOD == 0 || METHOD == 1, "histogram method");
+    constexpr int QB = 2 * NW;                                  // quartets per block
+    constexpr bool PARK_T = METHOD == 1;
+    __shared__ uint4 shared_ab[2][SHARED_SLOTS];
+    __shared__ uint32_t hist_all[NW][2][256];
+    __shared__ uint32_t park_all[NW][WAVE * 8];
+    const int tid = threadIdx.x;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    uint32_t *hist0 = hist_all[w][0], *hist1 = hist_all[w][1];
+    uint8_t *park = reinterpret_cast<uint8_t *>(park_all[w]) + lane * 4;
+    for (int i = lane; i < 512; i += WAVE) hist0[i] = 0;
+    const uint32_t T = (uint32_t)d.T;
+    const int last = d.ntiles - 1;
+    const int64_t nblk = (Q + QB - 1) / QB;
+    const uint8_t *rows = d.rows;
+    const uint8_t *nib = d.nib;
+    const uint8_t *planes = reinterpret_cast<const uint8_t *>(d.planes);
+    const uint8_t *planes3 = reinterpret_cast<const uint8_t *>(d.planes3);
+    const uint32_t pitch = (uint32_t)d.pitch, npitch = pitch / 2, wpitch = (uint32_t)d.W * 16u,
+                   w3pitch = (uint32_t)d.W * 12u;
+    constexpr int NJOB = 2, JPW = (NJOB + NW - 1) / NW;
+    __syncthreads();
+
+    const int64_t nslot = xcd_chunk > 0 ? 8 * xcd_chunk : nblk;
+    for (int64_t blk0 = blockIdx.x; blk0 < nslot; blk0 += gridDim.x) {
+        int64_t blk = blk0;
+        if (xcd_chunk > 0) {
+            const int64_t x = blk0 & 7, j = blk0 >> 3;
+            blk = x * xcd_chunk + j;
+            if (j >= xcd_chunk || blk >= nblk) continue;       // uniform for the whole workgroup
+        }
+        // leader = first quartet of the block; its (a,b) is what the workgroup shares
+        const int64_t it0 = blk * QB;
+        const int64_t lqi = order ? (int64_t)order[it0] : it0;
+        const uint4 lq = reinterpret_cast<const uint4 *>(quartets)[lqi];
+        uint32_t la = __builtin_amdgcn_readfirstlane(lq.x), lb = __builtin_amdgcn_readfirstlane(lq.y);
+        const bool leader_ok = (la < T) & (lb < T);
+        if (!leader_ok) la = lb = 0;
+        // this wave's two quartets (everything about them is wave-uniform)
+        bool have[2], work[2], shares[2];
+        int64_t qi[2];
+        uint32_t qa[2], qb[2], qc[2], qd[2];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int64_t it = it0 + 2 * w + k;
+            have[k] = it < Q;
+            qi[k] = have[k] ? (order ? (int64_t)order[it] : it) : 0;
+            const uint4 qv = reinterpret_cast<const uint4 *>(quartets)[qi[k]];
+            qa[k] = __builtin_amdgcn_readfirstlane(qv.x);
+            qb[k] = __builtin_amdgcn_readfirstlane(qv.y);
+            qc[k] = __builtin_amdgcn_readfirstlane(qv.z);
+            qd[k] = __builtin_amdgcn_readfirstlane(qv.w);
+            const bool bad = (qa[k] >= T) | (qb[k] >= T) | (qc[k] >= T) | (qd[k] >= T);
+            work[k] = have[k] && !bad;
+            shares[k] = work[k] && leader_ok && qa[k] == la && qb[k] == lb;
+            if (!work[k]) qc[k] = qd[k] = 0;
+        }
+        const bool any_work = work[0] | work[1];
+        const bool same_c = work[0] && work[1] && qc[0] == qc[1];      // row c of the second quartet = the first one's
+        const uint32_t l16 = (uint32_t)lane * 16u, l12 = (uint32_t)lane * 12u;
+        const uint32_t oc0 = qc[0] * npitch + l16, od0 = qd[0] * npitch + l16, oc1 = qc[1] * npitch + l16,
+                       od1 = qd[1] * npitch + l16;
+        const uint32_t pc0 = qc[0] * w3pitch + l12, pd0 = qd[0] * w3pitch + l12, pc1 = qc[1] * w3pitch + l12,
+                       pd1 = qd[1] * w3pitch + l12;
+        auto job_of = [=](int i) { return w + i * NW; };                       // wave-uniform
+        auto fetch_x = [=](int job, int tile) -> uint4 {
+            if (job == 0) return ld16(nib, la * npitch + l16 + (uint32_t)tile * (TILE / 2));
+            if (job == 1) return ld16(planes, la * wpitch + l16 + (uint32_t)tile * (WAVE * 16));
+            return make_uint4(0, 0, 0, 0);
+        };
+        auto fetch_y = [=](int job, int tile) -> uint4 {
+            if (job == 0) return ld16(nib, lb * npitch + l16 + (uint32_t)tile * (TILE / 2));
+            if (job == 1) return ld16(planes, lb * wpitch + l16 + (uint32_t)tile * (WAVE * 16));
+            return make_uint4(0, 0, 0, 0);
+        };
+        auto publish = [=](uint4 *buf, int job, uint4 x, uint4 y) {
+            if (job == 0) {
+                const uint32_t h = 0xF0F0F0F0u;
+                const uint32_t s0 = (x.x << 2) + y.x, s1 = (x.y << 2) + y.y, s2 = (x.z << 2) + y.z, s3 = (x.w << 2) + y.w;
+                buf[lane] = make_uint4((s0 << 4) & h, s0 & h, (s1 << 4) & h, s1 & h);
+                buf[64 + lane] = make_uint4((s2 << 4) & h, s2 & h, (s3 << 4) & h, s3 & h);
+            } else if (job == 1) {
+                buf[128 + lane] = make_uint4(x.y, x.z, x.x | y.x, (x.y ^ y.y) | (x.z ^ y.z));
+                reinterpret_cast<uint32_t *>(buf + 192)[lane] = x.w;
+            }
+        };
+        // own rows of both quartets for one step: c0, d0, d1 and -- unless it is c0 again -- c1
+        auto load_mine = [=](OwnRegs &r0, OwnRegs &r1_, int tile) {
+            if (!any_work) return;
+            const uint32_t tn = (uint32_t)tile * (TILE / 2), tp = (uint32_t)tile * (WAVE * 12);
+            r0.c = ld16(nib, oc0 + tn);
+            r0.d = ld16(nib, od0 + tn);
+            r0.pc = ld12(planes3, pc0 + tp);
+            r0.pd = ld12(planes3, pd0 + tp);
+            r1_.d = ld16(nib, od1 + tn);
+            r1_.pd = ld12(planes3, pd1 + tp);
+            if (!same_c) {
+                r1_.c = ld16(nib, oc1 + tn);
+                r1_.pc = ld12(planes3, pc1 + tp);
+            }
+        };
+
+        uint4 sx[JPW], sy[JPW];
+#pragma unroll
+        for (int i = 0; i < JPW; ++i) {
+            sx[i] = fetch_x(job_of(i), 0);
+            sy[i] = fetch_y(job_of(i), 0);
+        }
+        OwnRegs A0, A1;
+        A1.c = make_uint4(0, 0, 0, 0);
+        A1.pc = make_uint4(0, 0, 0, 0);
+        load_mine(A0, A1, 0);
+#pragma unroll
+        for (int i = 0; i < JPW; ++i) publish(shared_ab[0], job_of(i), sx[i], sy[i]);
+        uint32_t carry0 = 0, carry1 = 0;
+        __syncthreads();
+
+        for (int t = 0; t < d.ntiles; ++t) {
+            const int tn = min(t + 1, last);
+#pragma unroll
+            for (int i = 0; i < JPW; ++i) {
+                sx[i] = fetch_x(job_of(i), tn);
+                sy[i] = fetch_y(job_of(i), tn);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (any_work) {
+                // the shared image of this step: read once for both quartets
+                uint4 im0 = make_uint4(0, 0, 0, 0), im1 = im0, imr = im0;
+                uint32_t imB = 0;
+                if (shares[0] | shares[1]) {
+                    const uint4 *buf = shared_ab[t & 1];
+                    im0 = buf[lane];
+                    im1 = buf[64 + lane];
+                    imr = buf[128 + lane];
+                    imB = reinterpret_cast<const uint32_t *>(buf + 192)[lane];
+                }
+                auto one = [&](int k, const uint4 &cc, const uint4 &dd, const uint4 &pcc, const uint4 &pdd, uint32_t &carry,
+                               uint32_t *hist, auto &&hook) {
+                    uint4 ab0 = im0, ab1 = im1, r1 = imr;
+                    uint32_t Bw = imB;
+                    if (!shares[k]) {                           // group boundary: private rows a and b
+                        const uint32_t o0 = qa[k] * pitch + (uint32_t)t * TILE + l16;
+                        const uint32_t o1 = qb[k] * pitch + (uint32_t)t * TILE + l16;
+                        const uint4 a0 = ld16(rows, o0), a1 = ld16(rows, o0 + 1024u);
+                        const uint4 b0 = ld16(rows, o1), b1 = ld16(rows, o1 + 1024u);
+                        ab0 = make_uint4(((a0.x << 2) + b0.x) << 4, ((a0.y << 2) + b0.y) << 4, ((a0.z << 2) + b0.z) << 4,
+                                         ((a0.w << 2) + b0.w) << 4);
+                        ab1 = make_uint4(((a1.x << 2) + b1.x) << 4, ((a1.y << 2) + b1.y) << 4, ((a1.z << 2) + b1.z) << 4,
+                                         ((a1.w << 2) + b1.w) << 4);
+                        const uint4 pa = ld16(planes, qa[k] * wpitch + (uint32_t)t * (WAVE * 16) + l16);
+                        const uint4 pb = ld16(planes, qb[k] * wpitch + (uint32_t)t * (WAVE * 16) + l16);
+                        r1 = make_uint4(pa.y, pa.z, pa.x | pb.x, (pa.y ^ pb.y) | (pa.z ^ pb.z));
+                        Bw = pa.w;
+                    }
+                    const uint32_t C = count_mask_shared<SUB>(r1, Bw, pcc, pdd, lane, carry);
+                    uint32_t m;
+                    asm("s_mov_b32 %0, 0x0f0f0f0f" : "=s"(m));
+                    const uint32_t s0 = (cc.x << 2) + dd.x, s1 = (cc.y << 2) + dd.y, s2 = (cc.z << 2) + dd.z,
+                                   s3 = (cc.w << 2) + dd.w;
+                    uint32_t pat[8];
+                    pat[0] = and_or(s0, m, ab0.x); pat[1] = and_or(s0 >> 4, m, ab0.y);
+                    pat[2] = and_or(s1, m, ab0.z); pat[3] = and_or(s1 >> 4, m, ab0.w);
+                    pat[4] = and_or(s2, m, ab1.x); pat[5] = and_or(s2 >> 4, m, ab1.y);
+                    pat[6] = and_or(s3, m, ab1.z); pat[7] = and_or(s3 >> 4, m, ab1.w);
+                    hist_patterns<1, METHOD, std::remove_reference_t<decltype(hook)>, PARK_T>(pat, C, hist, park, hook);
+                };
+                NoHook nohook;
+                if (work[0]) one(0, A0.c, A0.d, A0.pc, A0.pd, carry0, hist0, nohook);
+                // the rows of step t+1 are requested once the second quartet's patterns are parked: every register
+                // they land in is dead by then, and they fly under its walk and the next step's first quartet
+                auto hook = [&]() {
+                    load_mine(A0, A1, tn);
+                    __builtin_amdgcn_sched_barrier(0);
+                };
+                if (work[1]) {
+                    if (same_c) one(1, A0.c, A1.d, A0.pc, A1.pd, carry1, hist1, hook);
+                    else one(1, A1.c, A1.d, A1.pc, A1.pd, carry1, hist1, hook);
+                } else {
+                    hook();
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < JPW; ++i) publish(shared_ab[(t + 1) & 1], job_of(i), sx[i], sy[i]);
+            __syncthreads();
+        }
+        // store the 256 counts of both quartets and clear their histograms
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            uint32_t *hist = k ? hist1 : hist0;
+            if (have[k]) {
+                uint32_t *out = cm + qi[k] * 256;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int bin = lane + WAVE * j;
+                    __builtin_nontemporal_store(work[k] ? hist[bin] : 0u, &out[bin]);
+                    hist[bin] = 0;
+                }
+            }
+        }
+        __syncthreads();
+    }
+}

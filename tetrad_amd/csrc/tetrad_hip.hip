@@ -122,6 +122,7 @@ struct tq_ctx {
     int count_invariant = 0;        // 1: invariant sites (all four bases equal, none missing) are counted as well -- what the reference's
                                     // count kernels do when their caller's mask leaves such a site open (resolve_quartets.py:59-64);
                                     // the worker itself always masks them (:218).  One-wave-per-quartet kernel only.
+    int scan_pair = 0;              // 1: two quartets per wavefront (tq_scan_wg2_kernel)
     int park_t = 1;                 // 1 (default): transposed pattern park of the set-bit walk (conflict-free byte reads at the price of
                                     // 2 more VALU per counted site: c3 6.79 -> 6.42 ms); 0: lane-contiguous park (A/B)
     int share_c = 0;                // 1: scan kernel variant that also shares row c inside a workgroup (scan.hpp: SHC;
@@ -477,9 +478,33 @@ int launch_scan_wg(tq_ctx *ctx, const uint32_t *dq, const uint32_t *order, int64
     return TQ_OK;
 }
 
+template <bool SUB, int METHOD, int NW>
+int launch_scan_wg2(tq_ctx *ctx, const uint32_t *dq, const uint32_t *order, int64_t Q, hipStream_t stream)
+{
+    auto kern = tq_scan_wg2_kernel<SUB, METHOD, NW>;
+    const int64_t nblk = (Q + 2 * NW - 1) / (2 * NW);
+    int64_t grid = nblk, xcd_chunk = 0;
+    if (ctx->xcd_remap && nblk >= 64) {                      // one block per workgroup, XCD-contiguous
+        xcd_chunk = (nblk + 7) / 8;
+        grid = xcd_chunk * 8;
+    }
+    if (grid < 1) grid = 1;
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NW * WAVE), 0, stream, dev_data(ctx), dq, order, Q, ctx->d_cm,
+                       xcd_chunk);
+    TQ_HIP(ctx, hipGetLastError());
+    return TQ_OK;
+}
+
 int launch_scan_n(tq_ctx *ctx, const uint32_t *dq, const uint32_t *order, int64_t Q, int subsample,
                   hipStream_t stream)
 {
+    if (ctx->scan_pair && ctx->scan_wg == 4 && Q >= 64 && !ctx->count_invariant && !ctx->share_c && ctx->waves_per_cu == 0 &&
+        ctx->scan_method < 2 && (uint64_t)ctx->T * (uint64_t)ctx->Sp < 0xFFFF0000ull) {
+        const int m = ctx->scan_method < 0 ? (subsample ? 1 : 0) : ctx->scan_method;
+        if (subsample)
+            return m ? launch_scan_wg2<true, 1, 4>(ctx, dq, order, Q, stream) : launch_scan_wg2<true, 0, 4>(ctx, dq, order, Q, stream);
+        return m ? launch_scan_wg2<false, 1, 4>(ctx, dq, order, Q, stream) : launch_scan_wg2<false, 0, 4>(ctx, dq, order, Q, stream);
+    }
     if (ctx->scan_wg >= 2 && Q >= 64 && !ctx->count_invariant && (uint64_t)ctx->T * (uint64_t)ctx->Sp < 0xFFFF0000ull) {
         const int m = ctx->scan_method < 0 ? (subsample ? 1 : 0) : ctx->scan_method;
 #define TQ_WG_CASE(NW)                                                                                   \
@@ -1317,6 +1342,10 @@ int tq_set_option(tq_ctx *ctx, const char *name, int64_t value)
     }
     if (!strcmp(name, "count_invariant")) {
         ctx->count_invariant = value != 0;
+        return TQ_OK;
+    }
+    if (!strcmp(name, "scan_pair")) {
+        ctx->scan_pair = value != 0;
         return TQ_OK;
     }
     if (!strcmp(name, "park_t")) {

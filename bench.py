@@ -42,7 +42,7 @@ sys.path.insert(0, str(REPO))
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
 F64_VECTOR_PEAK_TFLOPS = 78.6  # 256 CU x 4 SIMD x 16 lanes x 2 flop x 2.4 GHz (tools/probe_valu.hip measures 74)
-L2_TO_CU_PEAK_GBS = 17800.0    # MI355X_MICROARCH.md "Indexed rows": rows shared out of the XCD's L2, 16.8-18.8 TB/s
+TA_CYCLES_PER_LOAD = 18        # tools/probe_ta.hip: cycles of a CU's texture-address path per vector load wave-instruction (x2..x4)
 
 
 def _cpu_worker(args):
@@ -140,17 +140,22 @@ def kernel_rooflines(kms: dict, calls: int, Q: int, S: int, sub: bool, cfg: str)
     per = {k: v / calls for k, v in kms.items()}
     out = []
     steps = -(-S // 2048)
-    scan_bytes = Q * steps * (3.5 + 3.75 / 4) * 1024
     if per.get("order", 0) > 0:
         out.append(dict(name="ordering (tq_key_kernel + radix sort)", ms=per["order"], bound="latency (~20 small launches)",
                         frac=None))
     if per.get("scan", 0) > 0:
-        ach = scan_bytes / (per["scan"] / 1e3) / 1e9
+        # vector load instructions a CU has to issue: per wave and 2048-site step 4 for the wave's own rows c, d (2 x 16 B
+        # nibble codes, 2 x 12 B plane records) + 4 per workgroup of 4 waves for the shared rows a, b; each costs the CU's
+        # texture-address path ~18 cycles whatever its width (tools/probe_ta.hip, profiles/r03_scan/probe_ta.txt)
+        loads = Q * steps * (4 + 4 / 4)
+        ta_ms = loads * TA_CYCLES_PER_LOAD / 256 / 2.4e9 * 1e3
         out.append(dict(name="tq_scan_wg_kernel", ms=per["scan"],
-                        bound="co-bound: l2->cu fabric (this model), LDS pipe and VALU issue (pmc shares below); cutting the "
-                              "bytes by 40 % made it slower (DESIGN.md 4.1)",
-                        achieved=ach, peak=L2_TO_CU_PEAK_GBS, unit="GB/s", frac=ach / L2_TO_CU_PEAK_GBS,
-                        model="4.4 KiB per quartet-step through the L2->CU path"))
+                        bound="co-bound: texture-address issue (this model), LDS array, VALU issue (pmc shares below)",
+                        achieved=loads / (per["scan"] / 1e3) / 1e9, peak=256 * 2.4 / TA_CYCLES_PER_LOAD,
+                        unit="G vector-load wave-instructions/s", frac=ta_ms / per["scan"],
+                        model=f"5 vector loads per quartet and 2048-site step x {TA_CYCLES_PER_LOAD} cycles of a CU's texture-address "
+                              f"path each = {ta_ms:.2f} ms at 2.4 GHz; with the histogram taken out the kernel runs at 95 % "
+                              f"TA-busy (profiles/r03_scan)"))
     if per.get("bidiag", 0) > 0:
         fl = 3 * Q * (8.0 / 3.0) * 16 ** 3
         ach = fl / (per["bidiag"] / 1e3) / 1e12
@@ -179,7 +184,7 @@ def kernel_rooflines(kms: dict, calls: int, Q: int, S: int, sub: bool, cfg: str)
             for k in out:
                 for name, v in info.get("kernels", {}).items():
                     if name in k["name"]:
-                        k["pmc"] = dict({x: v[x] for x in ("valu_busy", "lds_busy", "lds_conflict_share") if x in v},
+                        k["pmc"] = dict({x: v[x] for x in ("valu_busy", "lds_busy", "lds_conflict_share", "ta_busy") if x in v},
                                         source="profiles/pmc_busy_latest.json: " + str(info.get("source")),
                                         commit=info.get("commit"))
         except Exception:
@@ -646,11 +651,12 @@ def roofline_block(achieved, dominant_ms, bytes_per_launch, traffic, traffic_src
     singular-value kernels, and counter traffic over algorithmic bytes."""
     scan = next((k for k in kernels if k["name"].startswith("tq_scan")), None)
     pmc = (scan or {}).get("pmc") or {}
-    valu, lds = pmc.get("valu_busy"), pmc.get("lds_busy")
+    shares = {k: pmc.get(k + "_busy") for k in ("valu", "lds", "ta") if pmc.get(k + "_busy") is not None}
     binding, binding_frac = None, None
-    if valu is not None and lds is not None:
-        binding = "valu+lds" if abs(valu - lds) < 0.1 else ("valu" if valu > lds else "lds")
-        binding_frac = max(valu, lds)
+    if shares:
+        top = max(shares.values())
+        binding = "+".join(k for k, v in shares.items() if top - v < 0.1)      # every unit within 10 points of the busiest
+        binding_frac = top
     svd = [k for k in kernels if k["name"] in ("tq_bidiag_kernel", "tq_bdsqr_kernel")]
     svd_frac = None
     if svd and all(k.get("ms") for k in svd):
@@ -667,7 +673,7 @@ def roofline_block(achieved, dominant_ms, bytes_per_launch, traffic, traffic_src
            "traffic_over_algorithmic": (traffic / bytes_per_launch if traffic else None),
            "binding": binding, "binding_frac": binding_frac,
            "binding_source": (pmc.get("source"), pmc.get("commit")) if pmc else None,
-           "scan_l2_to_cu_frac": (scan or {}).get("frac"),
+           "scan_ta_issue_frac": (scan or {}).get("frac"),
            "svd_f64_frac": svd_frac,
            "hbm_copy_measured_GBs": hbm_copy,
            "scan_stage_ms_per_step": per_pass.get("order", 0) + per_pass.get("scan", 0),
@@ -710,7 +716,7 @@ def bench_c5(args, eng, torch, dist, dev, world, rank):
     runner.close()
     # the Generator advanced exactly as the reference's would: the same draws, replayed on a fresh Generator
     rng_check = None
-    if rank == 0 and args.sampler == "host" and (args.warmup + args.steps) <= 12:
+    if rank == 0 and args.sampler == "host" and (args.warmup + args.steps) <= 130:
         chk = np.random.default_rng(synth.CONFIG_SEEDS["c5"])
         for _ in range(args.warmup + args.steps):
             bootstrap.draw_replicate(len(spans), chk)                       # run_inference.py:117-123

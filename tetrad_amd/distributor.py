@@ -14,7 +14,7 @@ MI355X-native scheme of SURVEY.md section 8e:
     per piece, the gathered parts are regrouped into global order on the device and copied to the
     destination rank's host arrays -- all of that under the kernels of the next piece.  A replicate
     of up to ~3e5 quartets per rank is a single piece = one collective per replicate; large batches
-    use up to 8 pieces of >= 131k quartets per rank so that only the last piece's gather + D2H is
+    use up to 8 pieces of >= 300k quartets per rank so that only the last piece's gather + D2H is
     exposed.
 
 The per-rank compute step is injectable so that the partition / gather / regroup logic is
@@ -28,8 +28,11 @@ from typing import Callable, Iterable, Optional
 
 import numpy as np
 
-MIN_PART_ROWS = 131072         # a rank's part of a piece is at least this many quartets: the singular-value kernels of a
-                               # part then make >= 3 rounds over the chip (a wave per 64 matrices), so their tails stay small
+MIN_PART_ROWS = 300_000        # a rank's part of a piece is at least this many quartets: stage_svd cuts a part into two half-chunks
+                               # on two streams, and chunks under ~150k quartets pay the tails of their kernels (a wave per 64
+                               # matrices, data-dependent sweep counts).  Measured on one rank through the sharded path, 1e6 quartets
+                               # of c3 (tools/pieces_sweep.sh): 1 / 2 / 3 / 4 / 7 pieces = 92.5 / 93.9 / 94.3 / 93.3 / 84.2 M quartets/s;
+                               # more pieces hide more of the gather + D2H (which one rank cannot show), so: as many as stay >= 300k
 MAX_PIECES = 8
 
 

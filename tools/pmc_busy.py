@@ -48,6 +48,8 @@ def main():
                 e["valu_busy"] = round(m["SQ_ACTIVE_INST_VALU"] / busy, 4)
             if "SQ_LDS_IDX_ACTIVE" in m:
                 e["lds_busy"] = round(m["SQ_LDS_IDX_ACTIVE"] / busy, 4)
+            if "TA_TA_BUSY_sum" in m:       # texture-address path: every vector memory instruction passes it (tools/probe_ta.hip)
+                e["ta_busy"] = round(m["TA_TA_BUSY_sum"] / busy, 4)
         if m.get("SQ_LDS_IDX_ACTIVE") and "SQ_LDS_BANK_CONFLICT" in m:
             e["lds_conflict_share"] = round(m["SQ_LDS_BANK_CONFLICT"] / m["SQ_LDS_IDX_ACTIVE"], 4)
         out["kernels"][k] = e

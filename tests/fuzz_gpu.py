@@ -33,13 +33,16 @@ while time.time() < t_end:
     if rng.random() < 0.3:
         tmparr[rng.integers(T)] = 78     # an all-missing taxon
     Q = int(rng.choice([1, 3, 63, 64, 65, 255, 1000, 1024, 1025, int(rng.integers(1, 6000))]))
+    if rng.random() < 0.03:
+        Q = int(rng.integers(32768, 36000))      # large enough for the device sort + the shared-row image in sorted order
     q = np.sort(np.stack([rng.permutation(T)[:4] for _ in range(Q)]), axis=1).astype(np.uint32)
     if rng.random() < 0.5:
         q = q[np.lexsort((q[:, 3], q[:, 2], q[:, 1], q[:, 0]))]
     opts = {"scan_wg": int(rng.choice([0, 0, 1, 2, 8])), "batch": int(rng.choice([0, 0, 700])),
             "svd_method": int(rng.choice([1, 1, 0])), "xcd_remap": int(rng.integers(2)),
             "svd_chunk": int(rng.choice([0, 0, 1, 100, 1024])), "svd_streams": int(rng.choice([0, 0, 1])),
-            "share_c": int(rng.choice([0, 0, 1]))}
+            "share_c": int(rng.choice([0, 0, 1])), "park_t": int(rng.choice([1, 1, 0])), "scan_pair": int(rng.choice([0, 0, 1])),
+            "scan_method": int(rng.choice([-1, -1, 0, 1]))}
     for k, v in opts.items():
         eng.set_option(k, v)
     eng.set_data(tmparr, tmpmap)

@@ -124,8 +124,9 @@ __device__ __forceinline__ uint32_t lds_offset(const void *p) { return (uint32_t
 // TRANSPOSED park: the wave's 8 pattern dwords per lane are stored row-major [dword j][lane] (256-byte rows), so a
 // byte read touches bank (lane mod 32) whatever its site index -- conflict-free, where the lane-contiguous layout
 // (stride 36 bytes) pays 2.5 extra LDS cycles per read instruction on c3 (rocprofv3: SQ_LDS_BANK_CONFLICT of the
-// walk without atomics) -- at the price of two more vector instructions per counted site for the address
-// lanebase + (i >> 2) * 256 + (i & 3) = (lanebase + i) + (i >> 2) * 252.
+// walk without atomics) -- at the price of one more vector instruction per counted site for the address
+// lanebase + (i >> 2) * 256 + (i & 3): the wave's park is 2 KiB-aligned, so the address is a bit field
+// [k = i & 3 : bits 0-1][lane : 2-7][j = i >> 2 : 8-10][wave : 11+] = v_bfi(0x703, i | i << 6, lanebase).
 // Wave priority during the walk (s_setprio): a wave in its walk is a chain of LDS round trips, a wave outside it issues
 // vector instructions back to back; raised priority for the walking waves keeps the LDS pipe fed (c3 scan 5.99 -> 5.90 ms;
 // the opposite setting 6.05 ms; A/B builds with -DTQ_WALK_PRIO=0|1|2 through TQ_LIB_PATH).
@@ -148,7 +149,7 @@ __device__ __forceinline__ void walk_set_bits(uint32_t c, uint32_t park_off, uin
     if (ATOMICS && TRANSPOSED) {
         uint32_t t, i, j, b;
         uint64_t save;
-        uint32_t one = 1u, k252 = 252u;
+        uint32_t one = 1u, k252 = 0x703u;                       // address bits taken from the site index: k (0-1) and j (8-10)
         asm volatile(
             "s_mov_b64 %[save], exec\n\t"
             TQ_WALK_PRIO_ON
@@ -158,9 +159,8 @@ __device__ __forceinline__ void walk_set_bits(uint32_t c, uint32_t park_off, uin
             "0:\n\t"
             "v_ffbl_b32_e32 %[i], %[c]\n\t"
             "v_and_b32_e32 %[c], %[c], %[t]\n\t"
-            "v_lshrrev_b32_e32 %[j], 2, %[i]\n\t"
-            "v_add_u32_e32 %[i], %[park], %[i]\n\t"
-            "v_mad_u32_u24 %[i], %[j], %[k252], %[i]\n\t"
+            "v_lshl_or_b32 %[j], %[i], 6, %[i]\n\t"              // i = 4 j + k: j now also at bits 8-10 (k at 0-1)
+            "v_bfi_b32 %[i], %[k252], %[j], %[park]\n\t"         // bits 0-1 and 8-10 from there, the rest = lane base
             "ds_read_u8 %[b], %[i]\n\t"
             "v_add_co_u32_e32 %[t], vcc, -1, %[c]\n\t"
             "s_waitcnt lgkmcnt(0)\n\t"
@@ -253,13 +253,38 @@ __device__ __forceinline__ void hist_patterns(const uint32_t (&pat)[8], uint32_t
         after_build();
     } else if (METHOD == 0) {
         after_build();
+        if (NREP == 1) {
+            // one EXEC-masked ds_add per site slot, most significant bit first: v_add_co c, vcc, c, c shifts the count
+            // mask and hands the slot's bit over AS the lane mask (its carry-out), so a slot is 3 vector instructions
+            // (that add, the byte extract, the bin address) where the compiler's version tests the bit with an AND and
+            // a compare (4)
+            uint32_t c = C, a, one = 1u;
+            const uint32_t hist_off = lds_offset(hrep);
+            uint64_t save;
+            asm volatile("s_mov_b64 %0, exec" : "=s"(save));
+#define TQ_SLOT(J, K)                                                                                          \
+            asm volatile("v_add_co_u32_e32 %[c], vcc, %[c], %[c]\n\t"                                            \
+                         "v_bfe_u32 %[a], %[p], " #K "*8, 8\n\t"                                                  \
+                         "v_lshl_add_u32 %[a], %[a], 2, %[hist]\n\t"                                              \
+                         "s_and_b64 exec, %[save], vcc\n\t"                                                       \
+                         "ds_add_u32 %[a], %[one]\n\t"                                                            \
+                         "s_mov_b64 exec, %[save]"                                                                 \
+                         : [c] "+v"(c), [a] "=&v"(a)                                                               \
+                         : [p] "v"(pat[J]), [hist] "s"(hist_off), [one] "v"(one), [save] "s"(save)                 \
+                         : "vcc", "memory");
+#define TQ_SLOT4(J) TQ_SLOT(J, 3) TQ_SLOT(J, 2) TQ_SLOT(J, 1) TQ_SLOT(J, 0)
+            TQ_SLOT4(7) TQ_SLOT4(6) TQ_SLOT4(5) TQ_SLOT4(4) TQ_SLOT4(3) TQ_SLOT4(2) TQ_SLOT4(1) TQ_SLOT4(0)
+#undef TQ_SLOT4
+#undef TQ_SLOT
+        } else {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
+            for (int j = 0; j < 8; ++j) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                if (C & (1u << (4 * j + k)))
-                    __hip_atomic_fetch_add(&hrep[((pat[j] >> (8 * k)) & 0xFFu) * NREP], 1u, __ATOMIC_RELAXED,
-                                           __HIP_MEMORY_SCOPE_WORKGROUP);
+                for (int k = 0; k < 4; ++k) {
+                    if (C & (1u << (4 * j + k)))
+                        __hip_atomic_fetch_add(&hrep[((pat[j] >> (8 * k)) & 0xFFu) * NREP], 1u, __ATOMIC_RELAXED,
+                                               __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
             }
         }
     } else {
@@ -471,7 +496,7 @@ tq_scan_wg_kernel(DevData d, const uint32_t *__restrict__ quartets, const uint32
     // per dispatch, SQ_LDS_BANK_CONFLICT and the LDS-busy cycles unchanged to the digit, 6.42 -> 6.58 ms with the lower
     // occupancy -- profiles/r03_scan/)
     __shared__ uint32_t hist_all[NW][256];
-    __shared__ uint32_t park_all[NW][PARK_T ? WAVE * 8 : WAVE * PAT_STRIDE / 4];
+    __shared__ __attribute__((aligned(2048))) uint32_t park_all[NW][PARK_T ? WAVE * 8 : WAVE * PAT_STRIDE / 4];
     const int tid = threadIdx.x;
     // the wave's number as a scalar: everything derived from it (does this wave have a quartet, does it share the
     // leader's rows, its histogram) is then wave-uniform for the compiler too -- scalar branches instead of EXEC
@@ -722,7 +747,7 @@ tq_scan_wg2_kernel(DevData d, const uint32_t *__restrict__ quartets, const uint3
     constexpr bool PARK_T = METHOD == 1;
     __shared__ uint4 shared_ab[2][SHARED_SLOTS];
     __shared__ uint32_t hist_all[NW][2][256];
-    __shared__ uint32_t park_all[NW][WAVE * 8];
+    __shared__ __attribute__((aligned(2048))) uint32_t park_all[NW][WAVE * 8];
     const int tid = threadIdx.x;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63;

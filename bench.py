@@ -311,9 +311,32 @@ def launch_probe(args):
     else:
         seen, total = 1, 1
     if rank == 0:
-        print(json.dumps({"probe": True, "n_gpus": seen, "gpus_arg": args.gpus, "rank_sum": total,
+        emit({"probe": True, "n_gpus": seen, "gpus_arg": args.gpus, "rank_sum": total,
                           "local_ranks_distinct": True, "self_launched": bool(os.environ.get("TQ_BENCH_SELF_LAUNCHED")),
-                          "master_addr": os.environ.get("MASTER_ADDR")}), flush=True)
+                          "master_addr": os.environ.get("MASTER_ADDR")})
+
+
+_REAL_STDOUT = None
+
+
+def quiet_stdout():
+    """The contract is ONE JSON line on stdout.  Libraries write there too (RCCL prints a version banner when its first
+    communicator is made, gloo its connection report), so everything this process and its libraries write to fd 1 is sent
+    to stderr from here on, and `emit` writes the line to the real stdout."""
+    global _REAL_STDOUT
+    if _REAL_STDOUT is None:
+        sys.stdout.flush()
+        _REAL_STDOUT = os.dup(1)
+        os.dup2(2, 1)
+
+
+def emit(line: dict):
+    data = (json.dumps(line) + "\n").encode()
+    if _REAL_STDOUT is None:
+        sys.stdout.write(data.decode())
+        sys.stdout.flush()
+    else:
+        os.write(_REAL_STDOUT, data)
 
 
 def main(argv=None):
@@ -321,6 +344,7 @@ def main(argv=None):
     args = parse_args(argv)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
         raise SystemExit(launch_ranks(args, argv))
+    quiet_stdout()
 
     if args.launch_probe:
         return launch_probe(args)
@@ -638,7 +662,7 @@ def main(argv=None):
             line["cpu_baseline"] = cb
             line["parity_on_cpu_sample"] = parity
             line["gpu_over_cpu"] = value / cb["value"]
-        print(json.dumps(line), flush=True)
+        emit(line)
     if multi:
         dist.barrier()
         dist.destroy_process_group()
@@ -754,7 +778,7 @@ def bench_c5(args, eng, torch, dist, dev, world, rank):
             "flags": stats["flags"], "rng_state_matches_reference_draw_order": rng_check,
             "commit": git_head(),
         }
-        print(json.dumps(line), flush=True)
+        emit(line)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -1,6 +1,7 @@
 import sys, time
 import numpy as np
-sys.path.insert(0, "/root/repo")
+from pathlib import Path
+sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
 from tetrad_amd.engine import QuartetEngine
 from oracle import oracle as orc
 orc.build()

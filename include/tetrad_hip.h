@@ -204,14 +204,18 @@ int tq_timing_read_kernels(tq_ctx *ctx, double *ms, int n_ms, int64_t *calls);
  * svd_wpc (blocks per CU of the singular-value grids, 0 = one pass per block), svd_chunk (quartets per
  * pass of the singular-value stage = per result-copy piece, default 2^18), svd_streams (1 or 2: chunks alternate
  * between two streams so that one chunk's tail is filled by the next chunk; default 2), share_c (1: scan variant that also shares row c inside a
- * workgroup; measured slower, off), bdsqr_maxit (QR sweeps per
- * singular value before TQ_FLAG_NO_CONVERGENCE, default 60), phases (timing diagnostics).         */
+ * workgroup; measured slower, off), park_t (1, default: transposed, bank-conflict-free pattern park of the set-bit walk; 0: lane-
+ * contiguous park), scan_pair (1: two quartets per wavefront; measured slower, off), count_invariant (1: sites whose four bases
+ * are equal are counted too -- what the reference's count kernels do when their caller's mask leaves such a site open,
+ * resolve_quartets.py:59-64; one-wave kernel), bdsqr_maxit (QR sweeps per singular value before TQ_FLAG_NO_CONVERGENCE,
+ * default 60), bdsqr_stats (1: count rotation steps / issued lane-slots, read with tq_debug_fetch which = 3), phases
+ * (timing diagnostics).                                                                         */
 int tq_set_option(tq_ctx *ctx, const char *name, int64_t value);
 
 /* Test hook: copy the scratch of the last resolve call to the host.  which = 0: count slab
  * u32[n][256] of the last scan batch; 1: bidiagonals f64[3m][32] (d[16], e[16]); 2: singular values
- * f64[3m][16] (unsorted, sign bit = not converged), m = quartets of the last singular-value chunk.
- * No reference counterpart.                                                                    */
+ * f64[3m][16] (unsorted, sign bit = not converged), m = quartets of the last singular-value chunk; 3: the 8 u64 counters
+ * of option bdsqr_stats.  No reference counterpart.                                                                    */
 int tq_debug_fetch(tq_ctx *ctx, int which, void *dst, int64_t bytes);
 
 /* Text for the consumers right after the hot path (host code, no device involved).

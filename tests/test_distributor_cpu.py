@@ -57,6 +57,24 @@ def test_shard_plan_covers_every_row_once():
                         assert lo == min(P.start[i] + r * P.part[i], P.end[i]) and lo <= hi <= P.end[i]
 
 
+def test_piece_bounds_tile_the_batch_with_decreasing_sizes():
+    """Result pieces are contiguous, cover [0,Q) once and shrink by PIECE_RATIO (the last piece's gather + D2H is what a
+    step cannot hide); the automatic piece count keeps the last per-rank part above ~100k quartets."""
+    for Q in (1, 5, 9, 1000, 1_000_000, 5_000_000, 174_792_640):
+        for n in (1, 2, 3, 8):
+            b = D.piece_bounds(Q, n)
+            assert b[0][0] == 0 and b[-1][1] == Q and all(b[i][1] == b[i + 1][0] for i in range(len(b) - 1))
+            assert all(hi > lo for lo, hi in b) or Q < n
+            sizes = [hi - lo for lo, hi in b]
+            if Q >= 1000 * n and n > 1:
+                assert all(sizes[i] > sizes[i + 1] for i in range(n - 1))
+                assert abs(sizes[-1] / sizes[-2] - D.PIECE_RATIO) < 0.02
+    for Q, world in ((1_000_000, 1), (8_000_000, 8), (5_000_000, 8), (5_000_000, 2), (40_000_000, 8)):
+        P = D.ShardPlan(Q, world)
+        assert P.npieces >= 1 and (P.npieces == 1 or P.part[-1] >= 100_000)
+        assert P.npieces == 1 or P.part[0] >= 250_000
+
+
 def test_single_process_resolver_with_injected_compute(oracle):
     """world = 1, host compute: the piece / regroup logic alone (several pieces, ragged last part)."""
     g = load_golden("tree_T12_S2000")

@@ -370,6 +370,7 @@ def main(argv=None):
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group("gloo")
+        dist.barrier()                                            # communicator set-up happens here, never inside a timed step
         world, rank = dist.get_world_size(), dist.get_rank()      # what the collective library actually sees
         if world != args.gpus:
             raise SystemExit(f"--gpus {args.gpus} but the process group has {world} ranks")

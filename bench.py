@@ -267,23 +267,40 @@ def launch_ranks(args, argv) -> int:
         e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
         procs.append(subprocess.Popen([sys.executable, str(Path(__file__).resolve())] + list(argv), env=e,
                                       stdout=subprocess.PIPE if r == 0 else sys.stderr, stderr=sys.stderr))
+    import signal
     import threading
+
+    def on_signal(signum, _frame):                  # a launcher that is told to stop takes its ranks with it
+        raise SystemExit(128 + signum)
+
+    for sig in (signal.SIGTERM, signal.SIGINT, signal.SIGHUP):
+        signal.signal(sig, on_signal)
     out0 = []
     t = threading.Thread(target=lambda: out0.append(procs[0].stdout.read()), daemon=True)
     t.start()
     worst, alive = 0, set(range(n))
-    while alive:
-        for r in sorted(alive):
-            rc = procs[r].poll()
-            if rc is None:
-                continue
-            alive.discard(r)
-            if rc != 0 and worst == 0:
-                worst = rc if rc > 0 else 1
-                sys.stderr.write(f"bench.py: rank {r} exited with status {rc}; ending the other ranks\n")
-                for o in alive:
-                    procs[o].terminate()            # exact PIDs of our own children
-        time.sleep(0.05)
+    try:
+        while alive:
+            for r in sorted(alive):
+                rc = procs[r].poll()
+                if rc is None:
+                    continue
+                alive.discard(r)
+                if rc != 0 and worst == 0:
+                    worst = rc if rc > 0 else 1
+                    sys.stderr.write(f"bench.py: rank {r} exited with status {rc}; ending the other ranks\n")
+                    for o in alive:
+                        procs[o].terminate()            # exact PIDs of our own children
+            time.sleep(0.05)
+    finally:
+        for r in alive:                             # only on the way out through a signal / exception: never leave ranks behind
+            if procs[r].poll() is None:
+                procs[r].terminate()
+        for r in alive:
+            try:
+                procs[r].wait(timeout=10)
+            except subprocess.TimeoutExpired:
+                procs[r].kill()
     t.join(timeout=10)
     if out0:
         # the contract is ONE JSON line on stdout: anything else rank 0 wrote there (gloo's C++ side prints its
@@ -301,6 +318,10 @@ def launch_probe(args):
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     if os.environ.get("TQ_BENCH_PROBE_FAIL_RANK") == str(rank):
         raise SystemExit(7)
+    if os.environ.get("TQ_BENCH_PROBE_PIDFILE"):          # test hook: say who we are, then linger
+        with open(os.environ["TQ_BENCH_PROBE_PIDFILE"], "a") as f:
+            f.write(f"{os.getpid()}\n")
+        time.sleep(float(os.environ.get("TQ_BENCH_PROBE_SLEEP", "0")))
     if world > 1:
         dist.init_process_group("gloo")
         t = torch.tensor([rank + 1], dtype=torch.int64)

@@ -61,3 +61,30 @@ def test_mismatched_launcher_environment_is_refused():
     r = run_bench("--gpus", "4", "--launch-probe", env_extra={"WORLD_SIZE": "2", "RANK": "0"})
     # an external launcher with another world size: main() must not silently run something else
     assert r.returncode != 0 or json.loads(r.stdout.strip())["n_gpus"] != 4
+
+
+def test_a_terminated_launcher_takes_its_ranks_with_it(tmp_path):
+    """SIGTERM to the launching process (a driver's timeout) must end the ranks it started: none may stay behind."""
+    import signal
+    import time
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["TQ_BENCH_PROBE_SLEEP"] = "60"
+    pidfile = tmp_path / "pids"
+    env["TQ_BENCH_PROBE_PIDFILE"] = str(pidfile)
+    p = subprocess.Popen([sys.executable, str(REPO / "bench.py"), "--gpus", "2", "--launch-probe", "--backend", "gloo"],
+                         env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    deadline = time.time() + 60
+    while time.time() < deadline and (not pidfile.exists() or len(pidfile.read_text().split()) < 2):
+        time.sleep(0.2)
+    pids = [int(x) for x in pidfile.read_text().split()]
+    assert len(pids) == 2
+    p.send_signal(signal.SIGTERM)
+    assert p.wait(timeout=30) != 0
+    time.sleep(0.5)
+    for pid in pids:
+        try:
+            os.kill(pid, 0)
+            alive = True
+        except OSError:
+            alive = False
+        assert not alive, f"rank process {pid} survived its launcher"

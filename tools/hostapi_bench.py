@@ -1,6 +1,6 @@
 """PCIe-inclusive throughput of the host-buffer API at c3 size (warm)."""
 import sys, time
-sys.path.insert(0,'/root/repo')
+from pathlib import Path; sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
 import numpy as np, torch
 from tetrad_amd import synth
 from tetrad_amd.engine import QuartetEngine

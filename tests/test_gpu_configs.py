@@ -231,7 +231,8 @@ def test_scan_kernel_variants_agree_on_sorted_batches(cfg, nq):
     """Batches large enough to be sorted by (a,b,c) and scanned by the cooperative kernel with shared rows
     (>= 32 768 quartets): every alternative form of the scan kernel -- lane-contiguous pattern park, two quartets per
     wavefront, row c through LDS, 8-wave workgroups, EXEC-masked counting in subsample mode and the walk in full
-    mode -- must give bitwise the rows of the default form, in both modes."""
+    mode, bank-private counters (scan_pb.hpp, the default of full mode) in subsample mode -- must give bitwise the rows
+    of the default form, in both modes."""
     from tetrad_amd import synth
     from tetrad_amd.engine import QuartetEngine
     T, S, _ = synth.CONFIGS[cfg]
@@ -243,7 +244,7 @@ def test_scan_kernel_variants_agree_on_sorted_batches(cfg, nq):
         for sub in (True, False):
             base = eng.resolve(q, sub)
             for opts in ({"park_t": 0}, {"scan_pair": 1}, {"scan_pair": 1, "scan_method": 1 - int(sub)}, {"share_c": 1},
-                         {"scan_wg": 8}, {"scan_method": 1 - int(sub)}):
+                         {"scan_wg": 8}, {"scan_method": 1 - int(sub)}, {"scan_method": 6}, {"scan_method": int(sub)}):
                 for k, v in opts.items():
                     eng.set_option(k, v)
                 got = eng.resolve(q, sub)

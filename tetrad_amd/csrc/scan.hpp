@@ -89,8 +89,8 @@ __device__ __forceinline__ uint32_t count_mask(const uint4 &pa, const uint4 &pb,
 }
 
 // the same with the (a,b) part pre-combined by the workgroup: r1 = {p0a, p1a, Ma|Mb, (p0a^p0b)|(p1a^p1b)}
-template <bool SUB>
-__device__ __forceinline__ uint32_t count_mask_shared(const uint4 &r1, uint32_t B, const uint4 &pc, const uint4 &pd,
+template <bool SUB, typename PC>
+__device__ __forceinline__ uint32_t count_mask_shared(const uint4 &r1, uint32_t B, const PC &pc, const PC &pd,
                                                       int lane, uint32_t &tile_carry)
 {
     const uint32_t M = r1.z | pc.x | pd.x;
@@ -142,6 +142,9 @@ __device__ __forceinline__ uint32_t lds_offset(const void *p) { return (uint32_t
 #else
 #define TQ_WALK_PRIO_ON
 #define TQ_WALK_PRIO_OFF
+#endif
+#ifndef TQ_PARK_ADDTID
+#define TQ_PARK_ADDTID 1
 #endif
 template <bool ATOMICS = true, bool TRANSPOSED = false>
 __device__ __forceinline__ void walk_set_bits(uint32_t c, uint32_t park_off, uint32_t hist_off)
@@ -288,9 +291,32 @@ __device__ __forceinline__ void hist_patterns(const uint32_t (&pat)[8], uint32_t
             }
         }
     } else {
-        uint32_t *pw = reinterpret_cast<uint32_t *>(park);
+        if (PARK_T && NREP == 1 && TQ_PARK_ADDTID) {
+            // transposed park, row j = 64 consecutive dwords: exactly the addressing of ds_write_addtid_b32 (M0 + offset +
+            // 4 * lane, no address register).  An LDS store moves its address and data registers to the LDS at 2 cycles
+            // per dword per wave-instruction (MI355X_MICROARCH.md, LDS): 8 x 2 cycles here against 4 x 6 for the
+            // ds_write2st64_b32 pairs the compiler makes of the plain stores -- and tools/probe_slots.hip shows that this
+            // transfer, not the LDS array, is what an LDS instruction of this kernel costs.
+            const uint32_t base = __builtin_amdgcn_readfirstlane(lds_offset(park));     // lane 0's slot = the wave's row 0
+            asm volatile("s_mov_b32 m0, %[base]\n\t"
+                         "s_nop 0\n\t"
+                         "ds_write_addtid_b32 %[p0]\n\t"
+                         "ds_write_addtid_b32 %[p1] offset:256\n\t"
+                         "ds_write_addtid_b32 %[p2] offset:512\n\t"
+                         "ds_write_addtid_b32 %[p3] offset:768\n\t"
+                         "ds_write_addtid_b32 %[p4] offset:1024\n\t"
+                         "ds_write_addtid_b32 %[p5] offset:1280\n\t"
+                         "ds_write_addtid_b32 %[p6] offset:1536\n\t"
+                         "ds_write_addtid_b32 %[p7] offset:1792"
+                         :
+                         : [base] "s"(base), [p0] "v"(pat[0]), [p1] "v"(pat[1]), [p2] "v"(pat[2]), [p3] "v"(pat[3]),
+                           [p4] "v"(pat[4]), [p5] "v"(pat[5]), [p6] "v"(pat[6]), [p7] "v"(pat[7])
+                         : "memory", "m0");
+        } else {
+            uint32_t *pw = reinterpret_cast<uint32_t *>(park);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) pw[PARK_T ? j * WAVE : j] = pat[j];     // PARK_T: `park` = row 0 of the wave + lane * 4
+            for (int j = 0; j < 8; ++j) pw[PARK_T ? j * WAVE : j] = pat[j];     // PARK_T: `park` = row 0 of the wave + lane * 4
+        }
         after_build();
         if (NREP == 1) {
             walk_set_bits<METHOD != 4, PARK_T>(C, lds_offset(park), lds_offset(hrep));
@@ -421,9 +447,28 @@ tq_scan_kernel(DevData d, const uint32_t *__restrict__ quartets, const uint32_t 
 // from the byte rows instead; it still takes part in the loads and barriers.  On c3 the kernel keeps
 // VALU 77 %, LDS 78 % and the L2 -> CU path ~90 % busy at the same time.
 // ------------------------------------------------------------------------------------
+// LLVM vector types (HIP's uint3 / uint4 are structs of scalars): a value of such a type stays ONE 96- / 128-bit
+// register tuple through the loop, so the tuple a load writes and the loop-carried value coalesce.  With scalars the
+// allocator copied two words of each 12-byte record right behind the load -- and that copy dragged an `s_waitcnt vmcnt`
+// in front of the histogram phase: three of the four prefetch loads of every step were waited for a few instructions
+// after their issue (ISA of rounds 2-3).
+typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 struct OwnRegs {
-    uint4 c, d, pc, pd;      // nibble codes of rows c and d (32 sites each), their plane records (.w = 0)
+    u32x4 c, d;              // nibble codes of rows c and d (32 sites each)
+    u32x3 pc, pd;            // their plane records {miss, p0, p1}
 };
+struct OwnRegsS {            // the same as HIP structs (the two-quartets-per-wave kernel)
+    uint4 c, d, pc, pd;
+};
+__device__ __forceinline__ u32x4 ldv16(const uint8_t *base, uint32_t off)
+{
+    return *reinterpret_cast<const u32x4 *>(base + off);
+}
+__device__ __forceinline__ u32x3 ldv12(const uint8_t *base, uint32_t off)
+{
+    return *reinterpret_cast<const u32x3 *>(base + off);
+}
 
 // 16-byte load at a wave-uniform base + 32-bit per-lane byte offset (lets the compiler use the
 // SGPR-base addressing form instead of 64-bit VGPR pointer arithmetic for every load; the host
@@ -431,6 +476,13 @@ struct OwnRegs {
 __device__ __forceinline__ uint4 ld16(const uint8_t *base, uint32_t off)
 {
     return *reinterpret_cast<const uint4 *>(base + off);
+}
+
+// makes the compiler treat the four words as defined HERE (copies into store tuples and the waits for the loads that
+// produced them cannot be scheduled earlier)
+__device__ __forceinline__ void pin4(uint4 &v)
+{
+    asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w));
 }
 
 // (a & m) | c in one instruction; m must sit in an SGPR (the compiler emits v_and + v_or otherwise)
@@ -457,10 +509,10 @@ __device__ __forceinline__ void load_own(OwnRegs &r, const uint8_t *nib, const u
                                          const OwnOff &o, int tile)
 {
     const uint32_t tn = (uint32_t)tile * (TILE / 2), tp = (uint32_t)tile * (WAVE * 12);
-    r.c = ld16(nib, o.c + tn);                   // plain codes; the factor 4 is the shift of a v_lshl_add_u32
-    r.d = ld16(nib, o.d + tn);
-    r.pc = ld12(planes3, o.pc + tp);
-    r.pd = ld12(planes3, o.pd + tp);
+    r.c = ldv16(nib, o.c + tn);                  // plain codes; the factor 4 is the shift of a v_lshl_add_u32
+    r.d = ldv16(nib, o.d + tn);
+    r.pc = ldv12(planes3, o.pc + tp);
+    r.pd = ldv12(planes3, o.pd + tp);
 }
 
 // (c<<2|d) code bytes of 8 sites from one nibble dword of each row: lo = sites 0-3, hi = sites 4-7
@@ -618,93 +670,129 @@ tq_scan_wg_kernel(DevData d, const uint32_t *__restrict__ quartets, const uint32
         auto load_mine = [=](OwnRegs &r, int tile) {
             if (SHC && shc) {
                 const uint32_t tn = (uint32_t)tile * (TILE / 2), tp = (uint32_t)tile * (WAVE * 12);
-                r.d = ld16(nib, oo.d + tn);
-                r.pd = ld12(planes3, oo.pd + tp);
+                r.d = ldv16(nib, oo.d + tn);
+                r.pd = ldv12(planes3, oo.pd + tp);
             } else {
                 load_own(r, nib, planes3, oo, tile);
             }
         };
 
-        // prologue: step 0 into buffer 0
-        uint4 sx[JPW], sy[JPW];
-#pragma unroll
-        for (int i = 0; i < JPW; ++i) {
-            sx[i] = fetch_x(job_of(i), 0);
-            sy[i] = fetch_y(job_of(i), 0);
-        }
-        OwnRegs A;
-        load_mine(A, 0);
-#pragma unroll
-        for (int i = 0; i < JPW; ++i) publish(shared_ab[0], job_of(i), sx[i], sy[i]);
-        uint32_t tile_carry = 0;
-        __syncthreads();
-
-        auto step = [&](OwnRegs &own, int t, int tnext) {
-            if (!work) return;
-            uint4 ab0, ab1, r1;                            // abp panels (sites 0-15, 16-31), combined planes
-            uint32_t Bw;                                   // run-begin bits
-            if (shares) {
-                const uint4 *buf = shared_ab[t & 1];
-                ab0 = buf[lane];
-                ab1 = buf[64 + lane];
-                r1 = buf[128 + lane];
-                Bw = reinterpret_cast<const uint32_t *>(buf + 192)[lane];
-                if (SHC && shc) {
-                    own.c = buf[SHARED_SLOTS + lane];
-                    own.pc = buf[SHARED_SLOTS + 64 + lane];
-                }
-            } else {                                        // group boundary: private rows a and b
-                const uint32_t o0 = q[0] * pitch + (uint32_t)t * TILE + (uint32_t)lane * 16u;
-                const uint32_t o1 = q[1] * pitch + (uint32_t)t * TILE + (uint32_t)lane * 16u;
-                const uint4 a0 = ld16(rows, o0), a1 = ld16(rows, o0 + 1024u);
-                const uint4 b0 = ld16(rows, o1), b1 = ld16(rows, o1 + 1024u);
-                ab0 = make_uint4(((a0.x << 2) + b0.x) << 4, ((a0.y << 2) + b0.y) << 4, ((a0.z << 2) + b0.z) << 4,
-                                 ((a0.w << 2) + b0.w) << 4);
-                ab1 = make_uint4(((a1.x << 2) + b1.x) << 4, ((a1.y << 2) + b1.y) << 4, ((a1.z << 2) + b1.z) << 4,
-                                 ((a1.w << 2) + b1.w) << 4);
-                const uint4 pa = ld16(planes, q[0] * wpitch + (uint32_t)t * (WAVE * 16) + (uint32_t)lane * 16u);
-                const uint4 pb = ld16(planes, q[1] * wpitch + (uint32_t)t * (WAVE * 16) + (uint32_t)lane * 16u);
-                r1 = make_uint4(pa.y, pa.z, pa.x | pb.x, (pa.y ^ pb.y) | (pa.z ^ pb.z));
-                Bw = pa.w;
-            }
-            const uint32_t C = count_mask_shared<SUB>(r1, Bw, own.pc, own.pd, lane, tile_carry);
-            // own.c and own.d hold the codes of rows c and d, one site per nibble (codes are 0..3, so the packed
-            // word can be shifted as a whole): (c << 2) + d is the (c<<2|d) nibble, one v_lshl_add_u32 per dword;
-            // the (a<<6|b<<4) byte of the same site sits in the high nibbles of abp
-            // (the mask lives in an SGPR so that (s & m) | ab is one v_and_or_b32; as a literal it
-            // cannot be encoded in a three-operand instruction and costs a second one)
-            uint32_t m;
-            asm("s_mov_b32 %0, 0x0f0f0f0f" : "=s"(m));
-            const uint32_t s0 = (own.c.x << 2) + own.d.x, s1 = (own.c.y << 2) + own.d.y, s2 = (own.c.z << 2) + own.d.z,
-                           s3 = (own.c.w << 2) + own.d.w;
-            uint32_t pat[8];
-            pat[0] = and_or(s0, m, ab0.x); pat[1] = and_or(s0 >> 4, m, ab0.y);
-            pat[2] = and_or(s1, m, ab0.z); pat[3] = and_or(s1 >> 4, m, ab0.w);
-            pat[4] = and_or(s2, m, ab1.x); pat[5] = and_or(s2 >> 4, m, ab1.y);
-            pat[6] = and_or(s3, m, ab1.z); pat[7] = and_or(s3 >> 4, m, ab1.w);
-            auto hook = [&]() {
-                load_mine(own, tnext);
-                __builtin_amdgcn_sched_barrier(0);
-            };
-            hist_patterns<1, METHOD == 3 ? 1 : METHOD, decltype(hook), PARK_T>(pat, C, hist, park, hook);
-        };
-
-        for (int t = 0; t < d.ntiles; ++t) {
-            // the shared pieces of step t+1 go to registers now and to LDS after this step's work; the own
-            // rows of step t+1 are requested from inside step(), as soon as this step no longer needs the
-            // registers they land in (the index is clamped: the last step re-reads its own tile)
-            const int tn = min(t + 1, last);
-#pragma unroll
+        // The step loop exists in up to four copies chosen by wave-uniform facts that do not change inside it: SPEC = the
+        // wave's job (0, 1, none) for waves that work and share the leader's rows (FAST), and one generic copy for the rest
+        // (a wave at a group boundary of the sorted order, a wave without a quartet; every wave of the A/B forms with
+        // other job layouts).  Inside a FAST copy every load is unconditional, so the compiler's s_waitcnt counts are exact:
+        // with the job and the boundary case as branches INSIDE the loop it assumes the fewest loads in flight at every
+        // join and turns "wait for the rows requested a step ago" into vmcnt(0) -- the job waves then also wait for the
+        // image loads they issued a few instructions earlier, an L2 round trip per step (ISA of rounds 2-3).
+        auto run = [&](auto spec_tag, auto fast_tag) {
+            constexpr int SPEC = decltype(spec_tag)::value;      // -1: jobs by the wave's number at run time
+            constexpr bool FAST = decltype(fast_tag)::value;
+            auto jobx = [=](int i) { return SPEC >= 0 ? (i == 0 ? SPEC : NJOB) : job_of(i); };
+            // prologue: step 0 into buffer 0
+            uint4 sx[JPW], sy[JPW];
+    #pragma unroll
             for (int i = 0; i < JPW; ++i) {
-                sx[i] = fetch_x(job_of(i), tn);
-                sy[i] = fetch_y(job_of(i), tn);
+                sx[i] = fetch_x(jobx(i), 0);
+                sy[i] = fetch_y(jobx(i), 0);
             }
-            __builtin_amdgcn_sched_barrier(0);
-            step(A, t, tn);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int i = 0; i < JPW; ++i) publish(shared_ab[(t + 1) & 1], job_of(i), sx[i], sy[i]);
-            if (METHOD != 3) __syncthreads();      // METHOD 3 = timing diagnostic without the barrier
+            OwnRegs A;
+            load_mine(A, 0);
+    #pragma unroll
+            for (int i = 0; i < JPW; ++i) publish(shared_ab[0], jobx(i), sx[i], sy[i]);
+            uint32_t tile_carry = 0;
+            __syncthreads();
+
+            auto step = [&](OwnRegs &own, int t, int tnext) {
+                if (!(FAST || work)) return;
+                uint4 ab0, ab1, r1;                            // abp panels (sites 0-15, 16-31), combined planes
+                uint32_t Bw;                                   // run-begin bits
+                if (FAST || shares) {
+                    const uint4 *buf = shared_ab[t & 1];
+                    ab0 = buf[lane];
+                    ab1 = buf[64 + lane];
+                    r1 = buf[128 + lane];
+                    Bw = reinterpret_cast<const uint32_t *>(buf + 192)[lane];
+                    if (SHC && shc) {
+                        const uint4 cc = buf[SHARED_SLOTS + lane], pp = buf[SHARED_SLOTS + 64 + lane];
+                        own.c = u32x4{cc.x, cc.y, cc.z, cc.w};
+                        own.pc = u32x3{pp.x, pp.y, pp.z};
+                    }
+                } else {                                        // group boundary: private rows a and b
+                    const uint32_t o0 = q[0] * pitch + (uint32_t)t * TILE + (uint32_t)lane * 16u;
+                    const uint32_t o1 = q[1] * pitch + (uint32_t)t * TILE + (uint32_t)lane * 16u;
+                    const uint4 a0 = ld16(rows, o0), a1 = ld16(rows, o0 + 1024u);
+                    const uint4 b0 = ld16(rows, o1), b1 = ld16(rows, o1 + 1024u);
+                    ab0 = make_uint4(((a0.x << 2) + b0.x) << 4, ((a0.y << 2) + b0.y) << 4, ((a0.z << 2) + b0.z) << 4,
+                                     ((a0.w << 2) + b0.w) << 4);
+                    ab1 = make_uint4(((a1.x << 2) + b1.x) << 4, ((a1.y << 2) + b1.y) << 4, ((a1.z << 2) + b1.z) << 4,
+                                     ((a1.w << 2) + b1.w) << 4);
+                    const uint4 pa = ld16(planes, q[0] * wpitch + (uint32_t)t * (WAVE * 16) + (uint32_t)lane * 16u);
+                    const uint4 pb = ld16(planes, q[1] * wpitch + (uint32_t)t * (WAVE * 16) + (uint32_t)lane * 16u);
+                    r1 = make_uint4(pa.y, pa.z, pa.x | pb.x, (pa.y ^ pb.y) | (pa.z ^ pb.z));
+                    Bw = pa.w;
+                }
+                const uint32_t C = count_mask_shared<SUB>(r1, Bw, own.pc, own.pd, lane, tile_carry);
+                // own.c and own.d hold the codes of rows c and d, one site per nibble (codes are 0..3, so the packed
+                // word can be shifted as a whole): (c << 2) + d is the (c<<2|d) nibble, one v_lshl_add_u32 per dword;
+                // the (a<<6|b<<4) byte of the same site sits in the high nibbles of abp
+                // (the mask lives in an SGPR so that (s & m) | ab is one v_and_or_b32; as a literal it
+                // cannot be encoded in a three-operand instruction and costs a second one)
+                uint32_t m;
+                asm("s_mov_b32 %0, 0x0f0f0f0f" : "=s"(m));
+                const uint32_t s0 = (own.c.x << 2) + own.d.x, s1 = (own.c.y << 2) + own.d.y, s2 = (own.c.z << 2) + own.d.z,
+                               s3 = (own.c.w << 2) + own.d.w;
+                uint32_t pat[8];
+                pat[0] = and_or(s0, m, ab0.x); pat[1] = and_or(s0 >> 4, m, ab0.y);
+                pat[2] = and_or(s1, m, ab0.z); pat[3] = and_or(s1 >> 4, m, ab0.w);
+                pat[4] = and_or(s2, m, ab1.x); pat[5] = and_or(s2 >> 4, m, ab1.y);
+                pat[6] = and_or(s3, m, ab1.z); pat[7] = and_or(s3 >> 4, m, ab1.w);
+                // (the first barrier keeps the scheduler from hoisting the loads above the last uses of the old values: it
+                // then needs copies of the loaded words and puts them -- with their s_waitcnt -- right behind the loads, in
+                // front of the histogram phase: the ISA of rounds 2-3 waited for three of the four loads there in every step)
+                auto hook = [&]() {
+                    __builtin_amdgcn_sched_barrier(0);
+                    load_mine(own, tnext);
+                    __builtin_amdgcn_sched_barrier(0);
+                };
+                hist_patterns<1, METHOD == 3 ? 1 : METHOD, decltype(hook), PARK_T>(pat, C, hist, park, hook);
+            };
+
+            for (int t = 0; t < d.ntiles; ++t) {
+                // the shared pieces of step t+1 go to registers now and to LDS after this step's work; the own
+                // rows of step t+1 are requested from inside step(), as soon as this step no longer needs the
+                // registers they land in (the index is clamped: the last step re-reads its own tile)
+                const int tn = min(t + 1, last);
+    #pragma unroll
+                for (int i = 0; i < JPW; ++i) {
+                    sx[i] = fetch_x(jobx(i), tn);
+                    sy[i] = fetch_y(jobx(i), tn);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                step(A, t, tn);
+                __builtin_amdgcn_sched_barrier(0);
+    #pragma unroll
+                for (int i = 0; i < JPW; ++i) {
+                    // the image words of step t+1 are "defined" here for the compiler: the copies that assemble the 16-byte LDS
+                    // stores (and the s_waitcnt they need) land here and not right behind the loads at the top of the step
+                    if (jobx(i) < NJOB) {
+                        pin4(sx[i]);
+                        pin4(sy[i]);
+                    }
+                    publish(shared_ab[(t + 1) & 1], jobx(i), sx[i], sy[i]);
+                }
+                if (METHOD != 3) __syncthreads();      // METHOD 3 = timing diagnostic without the barrier
+            }
+        };
+        {
+            using std::integral_constant;
+            constexpr bool CAN_SPEC = !SHC && JPW == 1 && NW >= 2;
+            if (CAN_SPEC && shares) {
+                if (w == 0) run(integral_constant<int, 0>{}, integral_constant<bool, true>{});
+                else if (w == 1) run(integral_constant<int, 1>{}, integral_constant<bool, true>{});
+                else run(integral_constant<int, CAN_SPEC ? NJOB : -1>{}, integral_constant<bool, true>{});
+            } else {
+                run(integral_constant<int, -1>{}, integral_constant<bool, false>{});
+            }
         }
         // store the 256 counts of this wave's quartet and clear its histogram
         if (have) {
@@ -830,7 +918,7 @@ tq_scan_wg2_kernel(DevData d, const uint32_t *__restrict__ quartets, const uint3
             }
         };
         // own rows of both quartets for one step: c0, d0, d1 and -- unless it is c0 again -- c1
-        auto load_mine = [=](OwnRegs &r0, OwnRegs &r1_, int tile) {
+        auto load_mine = [=](OwnRegsS &r0, OwnRegsS &r1_, int tile) {
             if (!any_work) return;
             const uint32_t tn = (uint32_t)tile * (TILE / 2), tp = (uint32_t)tile * (WAVE * 12);
             r0.c = ld16(nib, oc0 + tn);
@@ -851,7 +939,7 @@ tq_scan_wg2_kernel(DevData d, const uint32_t *__restrict__ quartets, const uint3
             sx[i] = fetch_x(job_of(i), 0);
             sy[i] = fetch_y(job_of(i), 0);
         }
-        OwnRegs A0, A1;
+        OwnRegsS A0, A1;
         A1.c = make_uint4(0, 0, 0, 0);
         A1.pc = make_uint4(0, 0, 0, 0);
         load_mine(A0, A1, 0);

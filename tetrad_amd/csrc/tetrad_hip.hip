@@ -52,6 +52,7 @@ namespace {
 #include "common.hpp"
 #include "prepare.hpp"
 #include "scan.hpp"
+#include "scan_pb.hpp"
 #include "jacobi.hpp"
 #include "hqr.hpp"
 #include "bootstrap.hpp"
@@ -143,7 +144,9 @@ struct tq_ctx {
     int nrep = 1;
     int waves_per_cu = 0;           // 0 = from the occupancy query
     int phases = 3;                 // diagnostics only: 1 = scan kernel only, 2 = SVD kernel only
-    int scan_method = -1;           // 0 = EXEC-masked slot per site, 1 = set-bit walk, -1 = 1 if subsample else 0
+    int scan_method = -1;           // 0 = EXEC-masked slot per site, 1 = set-bit walk, 6 = bank-private counters (scan_pb.hpp,
+                                    // A/B form; 0 / 1 where it does not apply); -1 = 1 if subsample else 0
+    int pb_ok = 0;                  // tq_scan_pb_kernel's counters sit on a 64 KiB LDS boundary (probed once in tq_create)
     int64_t batch = 1 << 23;        // quartets per scan batch (8 GiB count slab)
     // timing: a sequence of tagged HIP events on the launch stream; the time between two consecutive
     // marks is attributed to the tag of the later one (TAG_ORIGIN starts a sequence)
@@ -478,6 +481,46 @@ int launch_scan_wg(tq_ctx *ctx, const uint32_t *dq, const uint32_t *order, int64
     return TQ_OK;
 }
 
+// bank-private counters (scan_pb.hpp): one block of 4 quartets per workgroup, as launch_scan_wg
+template <bool SUB>
+int launch_scan_pb(tq_ctx *ctx, const uint32_t *dq, const uint32_t *order, int64_t Q, hipStream_t stream)
+{
+    auto kern = tq_scan_pb_kernel<SUB>;
+    const int64_t nblk = (Q + PB_NW - 1) / PB_NW;
+    int64_t grid = nblk, xcd_chunk = 0;
+    if (ctx->xcd_remap && nblk >= 64) {                      // one block per workgroup, XCD-contiguous
+        xcd_chunk = (nblk + 7) / 8;
+        grid = xcd_chunk * 8;
+    }
+    if (grid < 1) grid = 1;
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(PB_NW * WAVE), 0, stream, dev_data(ctx), dq, order, Q, ctx->d_cm,
+                       xcd_chunk, (uint32_t *)nullptr);
+    TQ_HIP(ctx, hipGetLastError());
+    return TQ_OK;
+}
+
+// One-time check (tq_create) that the kernel's counters start on a 64 KiB LDS boundary, which its address arithmetic
+// relies on: a launch with Q < 0 reports the offset and does nothing else.
+int probe_scan_pb(tq_ctx *ctx)
+{
+    uint32_t *d = nullptr, h[2] = {0, 0};
+    TQ_HIP(ctx, hipMalloc(&d, sizeof h));
+    hipError_t e = hipMemset(d, 0, sizeof h);
+    if (e == hipSuccess) {
+        DevData none{};
+        hipLaunchKernelGGL(tq_scan_pb_kernel<false>, dim3(1), dim3(PB_NW * WAVE), 0, 0, none, (const uint32_t *)nullptr,
+                           (const uint32_t *)nullptr, (int64_t)-1, (uint32_t *)nullptr, (int64_t)0, d);
+        hipLaunchKernelGGL(tq_scan_pb_kernel<true>, dim3(1), dim3(PB_NW * WAVE), 0, 0, none, (const uint32_t *)nullptr,
+                           (const uint32_t *)nullptr, (int64_t)-1, (uint32_t *)nullptr, (int64_t)0, d + 1);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpy(h, d, sizeof h, hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    if (e != hipSuccess) return fail(ctx, TQ_ERR_HIP, "probe of tq_scan_pb_kernel failed: %s", hipGetErrorString(e));
+    ctx->pb_ok = (h[0] == 0x80000000u && h[1] == 0x80000000u) ? 1 : -1;
+    return TQ_OK;
+}
+
 template <bool SUB, int METHOD, int NW>
 int launch_scan_wg2(tq_ctx *ctx, const uint32_t *dq, const uint32_t *order, int64_t Q, hipStream_t stream)
 {
@@ -505,8 +548,17 @@ int launch_scan_n(tq_ctx *ctx, const uint32_t *dq, const uint32_t *order, int64_
             return m ? launch_scan_wg2<true, 1, 4>(ctx, dq, order, Q, stream) : launch_scan_wg2<true, 0, 4>(ctx, dq, order, Q, stream);
         return m ? launch_scan_wg2<false, 1, 4>(ctx, dq, order, Q, stream) : launch_scan_wg2<false, 0, 4>(ctx, dq, order, Q, stream);
     }
+    // bank-private counters (option scan_method = 6, an A/B form: conflict-free atomics, but an LDS atomic costs its 4
+    // cycles of operand transfer either way and the 64 KiB of counters leave two workgroups per CU -- measured slower,
+    // scan_pb.hpp); 16-bit counters, so only while a quartet has at most PB_MAX_TILES steps
+    const bool pb_fits = ctx->pb_ok == 1 && ctx->scan_wg == 4 && Q >= 64 && !ctx->count_invariant && !ctx->share_c &&
+                         !ctx->scan_pair && ctx->waves_per_cu == 0 && ctx->Sp / TILE <= PB_MAX_TILES &&
+                         (uint64_t)ctx->T * (uint64_t)ctx->Sp < 0xFFFF0000ull;
+    if (pb_fits && ctx->scan_method == 6)
+        return subsample ? launch_scan_pb<true>(ctx, dq, order, Q, stream) : launch_scan_pb<false>(ctx, dq, order, Q, stream);
     if (ctx->scan_wg >= 2 && Q >= 64 && !ctx->count_invariant && (uint64_t)ctx->T * (uint64_t)ctx->Sp < 0xFFFF0000ull) {
-        const int m = ctx->scan_method < 0 ? (subsample ? 1 : 0) : ctx->scan_method;
+        int m = ctx->scan_method < 0 ? (subsample ? 1 : 0) : ctx->scan_method;
+        if (m == 6) m = subsample ? 1 : 0;
 #define TQ_WG_CASE(NW)                                                                                   \
     if (ctx->scan_wg == NW) {                                                                            \
         if (m == 2) return launch_scan_wg<true, 2, NW>(ctx, dq, order, Q, stream);                       \
@@ -547,7 +599,7 @@ int launch_scan_n(tq_ctx *ctx, const uint32_t *dq, const uint32_t *order, int64_
                              : launch_scan<N, false, 0>(ctx, dq, order, Q, stream);                  \
         return subsample ? launch_scan<N, true, 1>(ctx, dq, order, Q, stream)                        \
                          : launch_scan<N, false, 1>(ctx, dq, order, Q, stream)
-    const int method = ctx->scan_method < 0 ? (subsample ? 1 : 0) : ctx->scan_method;
+    const int method = (ctx->scan_method < 0 || ctx->scan_method == 6) ? (subsample ? 1 : 0) : ctx->scan_method;
     switch (ctx->nrep) {
         TQ_SCAN_CASE(2);
         TQ_SCAN_CASE(4);
@@ -955,6 +1007,11 @@ int tq_create(tq_ctx **out, int device_id)
     if (e == hipSuccess) e = hipGetDeviceProperties(&ctx->prop, device_id);
     if (e != hipSuccess) {
         int rc = fail(nullptr, TQ_ERR_HIP, "device %d not usable: %s", device_id, hipGetErrorString(e));
+        delete ctx;
+        return rc;
+    }
+    if (int rc = probe_scan_pb(ctx)) {
+        g_create_err = ctx->err;
         delete ctx;
         return rc;
     }
@@ -1402,8 +1459,8 @@ int tq_set_option(tq_ctx *ctx, const char *name, int64_t value)
         return TQ_OK;
     }
     if (!strcmp(name, "scan_method")) {
-        if (value < -1 || value > 5)
-            return fail(ctx, TQ_ERR_INVALID_ARG, "scan_method must be -1 (auto), 0, 1 (or 2..5: timing diagnostics)");
+        if (value < -1 || value > 6)
+            return fail(ctx, TQ_ERR_INVALID_ARG, "scan_method must be -1 (auto), 0, 1, 6 (or 2..5: timing diagnostics)");
         ctx->scan_method = (int)value;
         return TQ_OK;
     }

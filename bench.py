@@ -124,6 +124,17 @@ def git_head() -> str:
         return f.read_text().strip() if f.exists() else "unknown"
 
 
+def library_path() -> str:
+    """The shared object this process mapped (an inherited TQ_LIB_PATH must show in the line), with the commit it was
+    built from when it is the in-tree library."""
+    from tetrad_amd import _lib
+    p = str(_lib.LOADED_PATH)
+    f = REPO / ".build_commit"
+    if p == str(_lib.LIB_PATH) and f.exists():
+        p += " (built at " + f.read_text().strip() + ")"
+    return p
+
+
 def kernel_rooflines(kms: dict, calls: int, Q: int, S: int, sub: bool, cfg: str):
     """roofline.kernels[]: per kernel the measured ms per pass (HIP events of THIS run) and the fraction
     (<= 1) of the roof that binds it, from a stated model of the work it has to do:
@@ -673,7 +684,7 @@ def main(argv=None):
                                        kernels, multi),
             "flags": {"zero_data": int((flags & 1).sum()), "degenerate": int(((flags & 2) > 0).sum()),
                       "no_convergence": int(((flags & 8) > 0).sum())},
-            "commit": git_head(),
+            "commit": git_head(), "library_path": library_path(),
         }
         line.update(extra)
         if args.phases in (1, 2):
@@ -798,7 +809,7 @@ def bench_c5(args, eng, torch, dist, dev, world, rank):
             "host_draw_ms_per_replicate_mean": float(np.mean(stats["host_ms"])),
             "main_thread_wait_for_draws_ms_mean": float(np.mean(stats["wait_ms"])),
             "flags": stats["flags"], "rng_state_matches_reference_draw_order": rng_check,
-            "commit": git_head(),
+            "commit": git_head(), "library_path": library_path(),
         }
         emit(line)
     if world > 1:

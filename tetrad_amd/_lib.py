@@ -8,6 +8,7 @@ from __future__ import annotations
 
 import ctypes
 import os
+import sys
 import shutil
 import subprocess
 from pathlib import Path
@@ -74,6 +75,7 @@ def _stamp_commit() -> None:
 
 
 _lib = None
+LOADED_PATH = None      # the file load() mapped (bench.py records it: an inherited TQ_LIB_PATH must show in the line)
 
 
 def load() -> ctypes.CDLL:
@@ -94,7 +96,11 @@ def load() -> ctypes.CDLL:
     # developer knob for A/B runs of alternative builds of the same source (tools/ab/*.so): never a fallback --
     # a path that does not exist fails exactly like a missing library
     alt = os.environ.get("TQ_LIB_PATH")
-    lib = ctypes.CDLL(alt if alt else str(LIB_PATH))
+    if alt:
+        print(f"tetrad_amd: TQ_LIB_PATH is set -- loading {alt} instead of {LIB_PATH}", file=sys.stderr)
+    global LOADED_PATH
+    LOADED_PATH = alt if alt else str(LIB_PATH)
+    lib = ctypes.CDLL(LOADED_PATH)
     c = ctypes
     vp, i64, i32 = c.c_void_p, c.c_int64, c.c_int
     lib.tq_create.argtypes = [c.POINTER(vp), i32]

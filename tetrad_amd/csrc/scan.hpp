@@ -509,10 +509,19 @@ __device__ __forceinline__ void load_own(OwnRegs &r, const uint8_t *nib, const u
                                          const OwnOff &o, int tile)
 {
     const uint32_t tn = (uint32_t)tile * (TILE / 2), tp = (uint32_t)tile * (WAVE * 12);
+#ifndef TQ_DIAG_NO_NIB
     r.c = ldv16(nib, o.c + tn);                  // plain codes; the factor 4 is the shift of a v_lshl_add_u32
     r.d = ldv16(nib, o.d + tn);
+#endif
     r.pc = ldv12(planes3, o.pc + tp);
     r.pd = ldv12(planes3, o.pd + tp);
+#ifdef TQ_DIAG_NO_NIB
+    // A/B build only (wrong results): the two nibble loads of the own rows dropped -- the upper bound of what a layout
+    // with ONE record per taxon and lane-step could gain on the load side, before its extra vector work
+    (void)nib; (void)tn;
+    r.c = u32x4{r.pc.y, r.pc.z, r.pc.y >> 2, r.pc.z >> 2} & 0x33333333u;      // base bits of other sites: uniform codes
+    r.d = u32x4{r.pd.y, r.pd.z, r.pd.y >> 2, r.pd.z >> 2} & 0x33333333u;
+#endif
 }
 
 // (c<<2|d) code bytes of 8 sites from one nibble dword of each row: lo = sites 0-3, hi = sites 4-7

@@ -46,39 +46,103 @@ TA_CYCLES_PER_LOAD = 18        # tools/probe_ta.hip: cycles of a CU's texture-ad
 
 
 def _cpu_worker(args):
-    """cpu_baseline leg: the oracle (port of resolve_quartets.py:191-265) on one host core."""
+    """cpu_baseline leg: the oracle (port of resolve_quartets.py:191-265) on one host core.
+    variant: "port" (compiled gather + masks + count in one C call, then the reference's svd + matrix_rank calls),
+    "tuned" (one batched values-only SVD per chunk), "faithful" (the reference's NumPy temporaries spelled out:
+    fancy-index row gather, two mask reductions, then the count kernel -- resolve_quartets.py:212-223)."""
     os.environ["OPENBLAS_NUM_THREADS"] = "1"
     from oracle import oracle as orc
-    tmparr, tmpmap, quartets, sub = args[:4]
-    tuned = len(args) > 4 and args[4]
+    if isinstance(args[0], np.ndarray) and args[0].ndim == 1:      # (row indices, variant): the data came with the fork
+        tmparr, tmpmap, allq, sub = _CPU_SHARED
+        quartets, variant = allq[args[0]], args[1]
+    else:
+        tmparr, tmpmap, quartets, sub = args[:4]
+        variant = args[4] if len(args) > 4 else "port"
     try:
         from threadpoolctl import threadpool_limits
         ctx = threadpool_limits(1)
     except Exception:  # pragma: no cover
         ctx = None
     t0 = time.perf_counter()
-    fn = orc.new_infer_resolved_quartets_batched if tuned else orc.new_infer_resolved_quartets
+    fn = {"port": orc.new_infer_resolved_quartets, "tuned": orc.new_infer_resolved_quartets_batched,
+          "faithful": orc.new_infer_resolved_quartets_numpy}[variant]
     _, rstat, rscor = fn(tmparr, tmpmap, quartets, sub)
     dt = time.perf_counter() - t0
     return dt, rstat, rscor
 
 
-def cpu_baseline(tmparr, tmpmap, quartets, sub, gpu_rstat, gpu_rscor, budget_s=15.0):
+_CPU_SHARED = None      # (tmparr, tmpmap, quartets, sub) of the running cpu_baseline leg: inherited by the forked workers
+
+
+def host_cores():
+    """(hardware threads this process may run on, threads per core, physical cores among them)."""
+    avail = sorted(os.sched_getaffinity(0))
+    cores = set()
+    tpc = 1
+    for c in avail:
+        try:
+            sib = open(f"/sys/devices/system/cpu/cpu{c}/topology/thread_siblings_list").read().strip()
+            ids = []
+            for part in sib.split(","):
+                lo, _, hi = part.partition("-")
+                ids += list(range(int(lo), int(hi or lo) + 1))
+            tpc = max(tpc, len(ids))
+            cores.add(min(ids))
+        except (OSError, ValueError):
+            cores.add(c)
+    return len(avail), tpc, max(1, len(cores))
+
+
+def cpu_quota_cores():
+    """CPU time this process's control group may use, in cores (cgroup v2 cpu.max / v1 cfs quota), or None when
+    unlimited.  The GPU boxes give a one-GPU job a share of the host (16 cores of 128): more worker processes than
+    that only divide the same CPU time (measured: 128 processes ran at 221 quartets/s each, 16 at 2 390)."""
+    for f, parse in (("/sys/fs/cgroup/cpu.max", lambda t: t.split()),
+                     ("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", None)):
+        try:
+            txt = open(f).read().strip()
+            if parse:
+                q, per = parse(txt)
+                if q == "max":
+                    return None
+                return float(q) / float(per)
+            q = float(txt)
+            if q <= 0:
+                return None
+            return q / float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read().strip())
+        except (OSError, ValueError):
+            continue
+    return None
+
+
+def cpu_baseline(tmparr, tmpmap, quartets, sub, gpu_rstat, gpu_rscor, budget_s=15.0, max_procs=0):
+    """The oracle timed on the host, one single-threaded process per PHYSICAL core this process may use (the
+    reference's engine model: one engine per core, BLAS pinned to one thread).  Three variants of the same path,
+    each on a bounded sample of the benchmark's own batch; the first one doubles as the parity check."""
     import multiprocessing as mp
     from oracle import oracle as orc
     orc.build()
-    cores = max(1, min(16, len(os.sched_getaffinity(0))))
-    # calibrate on one core, then size the sample for ~budget_s of wall time on all cores
+    threads, tpc, phys = host_cores()
+    quota = cpu_quota_cores()
+    cores = phys if quota is None else max(1, min(phys, int(round(quota))))
+    if max_procs > 0:
+        cores = max(1, min(phys, max_procs))
+
+    global _CPU_SHARED
+    _CPU_SHARED = (tmparr, tmpmap, quartets, sub)
+
+    def timed(idx_chunks, variant):
+        t0 = time.perf_counter()
+        with mp.get_context("fork").Pool(len(idx_chunks)) as pool:
+            res = pool.map(_cpu_worker, [(c, variant) for c in idx_chunks], chunksize=1)
+        # the slowest worker's own clock: pool start-up (forking a process that holds GPU mappings) is not CPU work
+        wall = min(time.perf_counter() - t0, max(r[0] for r in res))
+        return wall, np.concatenate([r[1] for r in res]), np.concatenate([r[2] for r in res])
+
+    # calibrate on one core, then size each sample for its share of the budget on all cores
     dt, _, _ = _cpu_worker((tmparr, tmpmap, quartets[:300], sub))
-    n = int(min(len(quartets), max(cores * 200, 300 / dt * cores * budget_s)))
-    chunks = np.array_split(np.arange(n), cores)
-    t0 = time.perf_counter()
-    with mp.get_context("fork").Pool(cores) as pool:
-        res = pool.map(_cpu_worker, [(tmparr, tmpmap, quartets[c], sub) for c in chunks])
-    # the slowest worker's own clock: pool start-up (forking a process that holds GPU mappings) is not CPU work
-    wall = min(time.perf_counter() - t0, max(r[0] for r in res))
-    rstat = np.concatenate([r[1] for r in res])
-    rscor = np.concatenate([r[2] for r in res])
+    n = int(min(len(quartets), max(cores * 100, 300 / dt * cores * budget_s * 0.6)))
+    wall, rstat, rscor = timed(np.array_split(np.arange(n), cores), "port")
     # the oracle doubles as the checker on this sample
     parity = dict(
         n=n,
@@ -96,22 +160,39 @@ def cpu_baseline(tmparr, tmpmap, quartets, sub, gpu_rstat, gpu_rscor, budget_s=1
         pass
     # second figure: the same path as a tuned CPU implementation would run it -- one
     # values-only LAPACK SVD per matrix for a whole chunk instead of the reference's two full ones
-    n2 = max(cores * 100, n // 4)
-    chunks2 = np.array_split(np.arange(n2), cores)
-    t0 = time.perf_counter()
-    with mp.get_context("fork").Pool(cores) as pool:
-        res2 = pool.map(_cpu_worker, [(tmparr, tmpmap, quartets[c], sub, True) for c in chunks2])
-    wall2 = min(time.perf_counter() - t0, max(r[0] for r in res2))
-    rstat2 = np.concatenate([r[1] for r in res2])
+    n2 = int(min(len(quartets), max(cores * 100, n // 2)))
+    wall2, rstat2, _ = timed(np.array_split(np.arange(n2), cores), "tuned")
     parity["tuned_cpu_variant_topology_equal"] = bool(np.array_equal(rstat2[:, 0], gpu_rstat[:n2, 0]))
-    return dict(value=n / wall, unit="quartets/s", cores=cores, host_cores_total=os.cpu_count(),
-                host_cores_available_to_this_process=len(os.sched_getaffinity(0)), cpu_model=model, kind="port",
+    # third figure: the reference-faithful interpreted structure (NumPy gather + two mask reductions per quartet)
+    n3 = int(min(len(quartets), max(cores * 30, n // 6)))
+    wall3, rstat3, _ = timed(np.array_split(np.arange(n3), cores), "faithful")
+    parity["reference_faithful_variant_topology_equal"] = bool(np.array_equal(rstat3[:, 0], gpu_rstat[:n3, 0]))
+    whole = cores >= phys
+    return dict(value=n / wall, unit="quartets/s", cores=cores,
+                whole_host=(n / wall if whole else None),
+                whole_host_extrapolated=(None if whole else n / wall / cores * phys),
+                whole_host_note=("measured on every physical core" if whole else
+                                 f"this job's control group allows {quota:.1f} cores of CPU time "
+                                 f"(cpu.max): {cores} worker processes measured, the whole-host figure is per_core x {phys} "
+                                 f"physical cores -- an extrapolation; more processes than the quota only share the same CPU "
+                                 f"time (bench.py --cpu-procs {phys} measures that: 28.3 k quartets/s on 128 processes "
+                                 f"against 38 k on 16, profiles/r04_final)"),
+                cpu_quota_cores=quota,
+                host_hardware_threads_available_to_this_process=threads, threads_per_core=tpc,
+                host_physical_cores_available_to_this_process=phys, host_cores_total=os.cpu_count(),
+                cpu_model=model, kind="port",
                 tuned_variant=dict(value=n2 / wall2, unit="quartets/s", cores=cores,
                                    what=f"first {n2} quartets, compiled count loop + one batched values-only "
                                         f"numpy.linalg.svd per chunk (no interpreter in the per-quartet loop "
                                         f"beyond one ctypes call)"),
-                sample=f"first {n} quartets of the same batch, {cores} processes x 1 thread, "
-                       f"oracle.new_infer_resolved_quartets (C count loop + numpy.linalg svd/matrix_rank)",
+                reference_faithful=dict(value=n3 / wall3, unit="quartets/s", cores=cores, per_core=n3 / wall3 / cores,
+                                        what=f"first {n3} quartets, oracle.new_infer_resolved_quartets_numpy: the "
+                                             f"reference's interpreted structure (resolve_quartets.py:212-223: NumPy "
+                                             f"fancy-index row gather + two mask reductions per quartet, compiled "
+                                             f"count loop standing in for numba, numpy.linalg svd + matrix_rank)"),
+                sample=f"first {n} quartets of the same batch, {cores} processes x 1 thread (one per physical core "
+                       f"this process may use), oracle.new_infer_resolved_quartets (C gather + masks + count loop, "
+                       f"numpy.linalg svd/matrix_rank)",
                 per_core=n / wall / cores), parity
 
 
@@ -229,6 +310,8 @@ def parse_args(argv=None):
     ap.add_argument("--quartets", type=int, default=0, help="quartets in the batch (0 = config default)")
     ap.add_argument("--full", action="store_true", help="subsample_snps=False")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--cpu-procs", type=int, default=0,
+                    help="processes of the cpu_baseline leg (0 = one per physical core this process may use)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo = rehearsal of the N>1 control flow on a box with fewer GPUs than ranks")
     ap.add_argument("--pieces", type=int, default=0, help="N > 1: result pieces per batch (0 = automatic)")
@@ -615,6 +698,18 @@ def main(argv=None):
             pageable_call()
         extra["pcie_inclusive_value_pageable_arrays"] = 3 * Q / (time.perf_counter() - t1)
         extra["pageable_api_equals_timed_path"] = bool(np.array_equal(out_pg[0], rstat) and np.array_equal(out_pg[1], rscor))
+        # the other mode of the same workload through the timed path (3 steps after one warm-up): the reference's
+        # DEFAULT is subsample_snps=False (cli_init.py:61 is store_true), north_star's primary is True -- the driver's
+        # record carries both
+        out_o = (pinned_empty((Q, 2), np.uint32), pinned_empty((Q, 3), np.float64), pinned_empty(Q, np.uint8))
+        eng.resolve_to_host(d_q.data_ptr(), Q, not sub, out=out_o)
+        t1 = time.perf_counter()
+        for _ in range(3):
+            eng.resolve_to_host(d_q.data_ptr(), Q, not sub, out=out_o)
+        other = 3 * Q / (time.perf_counter() - t1)
+        extra["subsample_mode_value" if not sub else "full_mode_value"] = other
+        extra["other_mode_flags"] = {"zero_data": int((out_o[2] & 1).sum()), "degenerate": int(((out_o[2] & 2) > 0).sum()),
+                                     "nsnps_mean": float(out_o[0][:, 1].mean())}
     else:
         r = run_sharded(wl, args.steps, args.warmup)
         elapsed, kms, launches, q_rank = r["elapsed"], r["kms"], r["launches"], r["n_local"]
@@ -689,12 +784,20 @@ def main(argv=None):
         line.update(extra)
         if args.phases in (1, 2):
             line["INVALID_diagnostic_phases"] = args.phases
-        if not args.no_cpu and args.phases in (0, 3) and not multi:      # CPU leg: rank 0 at N=1 only
+        n_diag = int(((flags & 16) > 0).sum())            # TQ_FLAG_INVALID_DIAGNOSTIC: the library marks such rows itself
+        if n_diag:
+            line["INVALID_diagnostic_rows"] = n_diag
+            line["INVALID_diagnostic_options"] = [kv for kv in args.opt if kv.split("=")[0] in ("scan_method", "phases")]
+        if not args.no_cpu and args.phases in (0, 3) and not n_diag and not multi:      # CPU leg: rank 0 at N=1 only
             quartets_np = np.array(quartets_h)
-            cb, parity = cpu_baseline(tmparr, tmpmap, quartets_np, sub, rstat, rscor)
+            cb, parity = cpu_baseline(tmparr, tmpmap, quartets_np, sub, rstat, rscor, max_procs=args.cpu_procs)
             line["cpu_baseline"] = cb
             line["parity_on_cpu_sample"] = parity
-            line["gpu_over_cpu"] = value / cb["value"]
+            line["gpu_over_cpu"] = value / cb["value"]                 # against the port on cb["cores"] cores
+            whole_cpu = cb["whole_host"] or cb["whole_host_extrapolated"]
+            line["gpu_over_cpu_whole_host"] = value / whole_cpu
+            line["gpu_over_cpu_whole_host_is_extrapolated"] = cb["whole_host"] is None
+            line["gpu_over_cpu_reference_faithful"] = value / cb["reference_faithful"]["value"]
         emit(line)
     if multi:
         dist.barrier()

@@ -22,6 +22,12 @@
  *     result D2H of one piece overlaps the kernels of the next.  *_dev entry points
  *     take device pointers, enqueue on the given HIP stream and return without
  *     synchronising.
+ *   - stream rule: the *_dev entry points of one context share its device scratch (count slab,
+ *     ordering and singular-value scratch, the replicate's layout).  The library orders them in CALL
+ *     order whatever their streams: a call on another stream than the previous *_dev call first makes
+ *     its stream wait for that call's work, and a host-buffer call waits for every *_dev call made
+ *     before it.  What the library cannot see is the caller's own use of the OUTPUT arrays of a *_dev
+ *     call: read them on the stream they were produced on, or after synchronising with it.
  */
 #ifndef TETRAD_HIP_H
 #define TETRAD_HIP_H
@@ -53,9 +59,13 @@ enum {
     TQ_FLAG_DEGENERATE = 2,    /* two lowest scores within 1e-9 * sigma_max: argmin is
                                   decided by SVD rounding noise in any implementation */
     TQ_FLAG_BAD_INDEX = 4,     /* a taxon index was >= T; row treated as zero-data   */
-    TQ_FLAG_NO_CONVERGENCE = 8 /* a singular-value iteration hit its sweep cap; the row holds the
+    TQ_FLAG_NO_CONVERGENCE = 8, /* a singular-value iteration hit its sweep cap; the row holds the
                                   unconverged values (reference: np.linalg.svd raises LinAlgError,
                                   resolve_quartets.py:242; the Python mirror raises it too)   */
+    TQ_FLAG_INVALID_DIAGNOSTIC = 16 /* the row was made while a timing-diagnostic mode was set (tq_set_option
+                                  "scan_method" 2..5 or "phases" 1 / 2): it is NOT a result.  Set on every row of
+                                  such a call; a call without a flags array fails while such a mode is set; the
+                                  Python mirror raises.                                        */
 };
 
 /* Create / destroy a context bound to HIP device `device_id`.
@@ -209,7 +219,9 @@ int tq_timing_read_kernels(tq_ctx *ctx, double *ms, int n_ms, int64_t *calls);
  * are equal are counted too -- what the reference's count kernels do when their caller's mask leaves such a site open,
  * resolve_quartets.py:59-64; one-wave kernel), bdsqr_maxit (QR sweeps per singular value before TQ_FLAG_NO_CONVERGENCE,
  * default 60), bdsqr_stats (1: count rotation steps / issued lane-slots, read with tq_debug_fetch which = 3), phases
- * (timing diagnostics).                                                                         */
+ * (timing diagnostics).  scan_method 2..5 and phases 1 / 2 are timing diagnostics whose rows are wrong: every row of a
+ * call made under them carries TQ_FLAG_INVALID_DIAGNOSTIC and a call without a flags array fails.  scan_method 6 = the
+ * bank-private counter kernel (scan_pb.hpp; an A/B form, slower).  batch is clamped to 2^31 - 1.          */
 int tq_set_option(tq_ctx *ctx, const char *name, int64_t value);
 
 /* Test hook: copy the scratch of the last resolve call to the host.  which = 0: count slab

@@ -292,3 +292,97 @@ def test_end_to_end_engine_rows_to_supertree(engine):
         nwk = qmc.infer_supertree_from_arrays(q, rscor, rstat, T, weights=1)
         truth, got = _bipartitions_from_children(children, root, T), _bipartitions_from_newick(nwk, T)
         assert len(got & truth) >= len(truth) - (0 if T == 16 else 2), (len(got & truth), len(truth))
+
+
+def test_diagnostic_modes_mark_every_row_and_refuse_unflagged_outputs():
+    """Timing-diagnostic modes (scan_method 2..5, phases 1 / 2) produce wrong rows.  None may leave the library
+    unmarked: every row carries TQ_FLAG_INVALID_DIAGNOSTIC, a device-API call without a flags array fails, the Python
+    mirror of the reference's worker raises, and resetting the option gives clean rows again."""
+    import torch
+    from tetrad_amd import _lib, synth
+    from tetrad_amd import resolve_quartets as RQ
+    from tetrad_amd.engine import QuartetEngine
+    T, S = 24, 6000
+    tmparr, tmpmap = synth.simulate_tmparr(T, S, 5)
+    q = synth.random_quartets(T, 4000, seed=2)
+    with QuartetEngine(0) as eng:
+        eng.set_data(tmparr, tmpmap)
+        clean = eng.resolve(q, True)
+        assert not (clean[2] & _lib.FLAG_INVALID_DIAGNOSTIC).any()
+        for name, value, default in (("scan_method", 2, -1), ("scan_method", 4, -1), ("scan_method", 5, -1),
+                                     ("phases", 1, 3), ("phases", 2, 3)):
+            eng.set_option(name, value)
+            _, _, flags = eng.resolve(q, True)
+            assert (flags & _lib.FLAG_INVALID_DIAGNOSTIC).all(), (name, value)
+            d_q = torch.from_numpy(q.view(np.int32)).cuda()
+            d_rstat = torch.zeros((len(q), 2), dtype=torch.int32, device="cuda")
+            d_rscor = torch.zeros((len(q), 3), dtype=torch.float64, device="cuda")
+            with pytest.raises(_lib.TetradHipError, match="diagnostic"):
+                eng.resolve_dev(d_q.data_ptr(), len(q), True, d_rstat.data_ptr(), d_rscor.data_ptr(), 0, 0)
+            torch.cuda.synchronize()
+            eng.set_option(name, default)
+        again = eng.resolve(q, True)
+        for a, b in zip(clean, again):
+            np.testing.assert_array_equal(a, b)
+    # the drop-in mirror (tetrad_amd.resolve_quartets) refuses such rows
+    eng = RQ.get_engine(0)
+    try:
+        eng.set_option("scan_method", 4)
+        with pytest.raises(RuntimeError, match="diagnostic"):
+            RQ.new_infer_resolved_quartets(tmparr, tmpmap, q[:2000], True)
+    finally:
+        eng.set_option("scan_method", -1)
+    RQ.new_infer_resolved_quartets(tmparr, tmpmap, q[:2000], True)
+
+
+def test_batch_option_is_clamped():
+    """`batch` reaches hipCUB as int: values beyond 2^31 - 1 are clamped, not wrapped."""
+    from tetrad_amd import synth
+    from tetrad_amd.engine import QuartetEngine
+    tmparr, tmpmap = synth.simulate_tmparr(12, 3000, 11)
+    q = synth.all_quartets(12)
+    with QuartetEngine(0) as eng:
+        eng.set_data(tmparr, tmpmap)
+        base = eng.resolve(q, True)
+        eng.set_option("batch", 1 << 40)
+        got = eng.resolve(q, True)
+        for a, b in zip(base, got):
+            np.testing.assert_array_equal(a, b)
+
+
+def test_device_api_calls_on_different_streams_and_host_api_are_ordered(oracle):
+    """The *_dev entry points of one context share its scratch.  A resolve enqueued on a side stream BEHIND a long-running
+    kernel, a second one on another stream right after it, then a host-API call with different quartets straight away:
+    every result must equal the oracle's (the library orders the calls in call order, include/tetrad_hip.h)."""
+    import torch
+    from tetrad_amd import synth
+    from tetrad_amd.engine import QuartetEngine
+    T, S = 20, 9000
+    tmparr, tmpmap = synth.simulate_tmparr(T, S, 8)
+    qa = synth.random_quartets(T, 3000, seed=1)
+    qb = synth.random_quartets(T, 3000, seed=2)
+    qc = synth.random_quartets(T, 3000, seed=3)
+    with QuartetEngine(0) as eng:
+        eng.set_data(tmparr, tmpmap)
+        s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+        dev = {}
+        for name, q in (("a", qa), ("b", qb)):
+            dev[name] = (torch.from_numpy(q.view(np.int32)).cuda(), torch.zeros((len(q), 2), dtype=torch.int32, device="cuda"),
+                         torch.zeros((len(q), 3), dtype=torch.float64, device="cuda"), torch.zeros(len(q), dtype=torch.uint8, device="cuda"))
+        torch.cuda.synchronize()
+        big = torch.empty(1 << 28, dtype=torch.float32, device="cuda")
+        with torch.cuda.stream(s1):
+            for _ in range(20):                      # tens of milliseconds of work in front of the first resolve
+                big.mul_(1.0001)
+        d = dev["a"]
+        eng.resolve_dev(d[0].data_ptr(), len(qa), True, d[1].data_ptr(), d[2].data_ptr(), d[3].data_ptr(), s1.cuda_stream)
+        d = dev["b"]
+        eng.resolve_dev(d[0].data_ptr(), len(qb), False, d[1].data_ptr(), d[2].data_ptr(), d[3].data_ptr(), s2.cuda_stream)
+        host = eng.resolve(qc, True)                 # host API: waits for both
+        torch.cuda.synchronize()
+        for (q, sub, rstat, rscor) in ((qa, True, dev["a"][1].cpu().numpy().view(np.uint32), dev["a"][2].cpu().numpy()),
+                                       (qb, False, dev["b"][1].cpu().numpy().view(np.uint32), dev["b"][2].cpu().numpy()),
+                                       (qc, True, host[0], host[1])):
+            _, o_rstat, o_rscor = oracle.new_infer_resolved_quartets(tmparr, tmpmap, q, sub)
+            np.testing.assert_array_equal(rstat[:, 1], o_rstat[:, 1])
+            np.testing.assert_allclose(rscor, o_rscor, rtol=1e-6, atol=1e-9)

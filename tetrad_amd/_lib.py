@@ -23,7 +23,7 @@ ERR_NAMES = {
     -1: "TQ_ERR_INVALID_ARG", -2: "TQ_ERR_NO_DEVICE", -3: "TQ_ERR_HIP",
     -4: "TQ_ERR_NO_DATA", -5: "TQ_ERR_LOCUS_ORDER", -6: "TQ_ERR_OOM",
 }
-FLAG_ZERO_DATA, FLAG_DEGENERATE, FLAG_BAD_INDEX, FLAG_NO_CONVERGENCE = 1, 2, 4, 8
+FLAG_ZERO_DATA, FLAG_DEGENERATE, FLAG_BAD_INDEX, FLAG_NO_CONVERGENCE, FLAG_INVALID_DIAGNOSTIC = 1, 2, 4, 8, 16
 
 #: every symbol include/tetrad_hip.h declares (checked by tests/test_cabi_symbols.py)
 SYMBOLS = [

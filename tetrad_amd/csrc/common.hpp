@@ -51,5 +51,6 @@ struct OutPtrs {
     uint32_t *cmats;    // [Q,3,16,16] or null (debug)
     double *svds;       // [Q,3,16] or null (debug)
     int32_t *ranks;     // [Q,3] or null (debug)
+    uint32_t flag_or;   // OR-ed into every row's flags (TQ_FLAG_INVALID_DIAGNOSTIC while a timing-diagnostic mode is set)
 };
 

@@ -513,6 +513,7 @@ tq_score_kernel(const double *__restrict__ sv, const uint32_t *__restrict__ nsnp
     const uint4 qv = reinterpret_cast<const uint4 *>(quartets)[q];
     const uint32_t Tu = (uint32_t)T;
     if ((qv.x >= Tu) | (qv.y >= Tu) | (qv.z >= Tu) | (qv.w >= Tu)) fl |= TQ_FLAG_BAD_INDEX;
+    fl |= out.flag_or;
     out.rstat[q * 2 + 0] = (uint32_t)topo;
     out.rstat[q * 2 + 1] = nsn;
     out.rscor[q * 3 + 0] = sc[0];

@@ -297,6 +297,7 @@ tq_svd_kernel(const uint32_t *__restrict__ cm, const uint32_t *__restrict__ quar
             const uint4 qv = reinterpret_cast<const uint4 *>(quartets)[myq];
             const uint32_t Tu = (uint32_t)T;
             if ((qv.x >= Tu) | (qv.y >= Tu) | (qv.z >= Tu) | (qv.w >= Tu)) fl |= TQ_FLAG_BAD_INDEX;
+            fl |= out.flag_or;
             out.rstat[myq * 2 + 0] = (uint32_t)topo;
             out.rstat[myq * 2 + 1] = my_nsnps;
             out.rscor[myq * 3 + 0] = sc[0];

@@ -140,6 +140,7 @@ struct tq_ctx {
     // and the host API makes sK wait for it before it touches any of them
     hipEvent_t evDevApi = nullptr;
     bool dev_api_pending = false;
+    hipStream_t last_dev_stream = nullptr;   // stream of the last device-API enqueue (enter_dev_api orders across streams)
     // options
     int nrep = 1;
     int waves_per_cu = 0;           // 0 = from the occupancy query
@@ -658,6 +659,11 @@ int launch_hqr(tq_ctx *ctx, const uint32_t *cm, const uint32_t *dq, int64_t n, c
     return mark(ctx, TAG_SCORE, stream, lane);
 }
 
+bool diagnostic_mode(const tq_ctx *ctx)
+{
+    return (ctx->scan_method >= 2 && ctx->scan_method <= 5) || ctx->phases != 3;
+}
+
 OutPtrs offset_out(const OutPtrs &o, int64_t q0)
 {
     OutPtrs r = o;
@@ -727,6 +733,11 @@ int stage_svd(tq_ctx *ctx, int64_t q0, int64_t n, bool debug, const OutPtrs &out
     const int64_t chunk = svd_chunk_rows(ctx, n);
     int rc = ensure_svd(ctx, chunk);
     if (rc) return rc;
+    // timing-diagnostic modes produce wrong rows: none leaves the library unmarked
+    const bool diag = diagnostic_mode(ctx);
+    if (diag && !out.flags)
+        return fail(ctx, TQ_ERR_INVALID_ARG, "a timing-diagnostic mode is set (scan_method 2..5 or phases 1 / 2): its rows are "
+                                             "not results and are only handed out with a flags array (TQ_FLAG_INVALID_DIAGNOSTIC)");
     const bool two = ctx->svd_streams > 1 && n > chunk;
     if (two) {
         TQ_HIP(ctx, hipEventRecord(ctx->evFork, stream));
@@ -737,10 +748,17 @@ int stage_svd(tq_ctx *ctx, int64_t q0, int64_t n, bool debug, const OutPtrs &out
         const int64_t cn = (n - c0) < chunk ? (n - c0) : chunk;
         const int lane = two ? (int)(ci & 1) : 0;
         hipStream_t st = lane ? ctx->sX : stream;
+        if (!(ctx->phases & 2)) {                   // no score kernel runs: flag the rows here
+            if (hipMemsetAsync(out.flags + c0, TQ_FLAG_INVALID_DIAGNOSTIC, (size_t)cn, st) != hipSuccess) {
+                rc = fail(ctx, TQ_ERR_HIP, "hipMemsetAsync(flags) failed");
+                break;
+            }
+        }
         if (ctx->phases & 2) {
             const uint32_t *cm = ctx->d_cm + (size_t)(q0 + c0) * 256;
             const uint32_t *dq = ctx->scanned_q + (q0 + c0) * 4;
-            const OutPtrs o = offset_out(out, c0);
+            OutPtrs o = offset_out(out, c0);
+            o.flag_or = diag ? (uint32_t)TQ_FLAG_INVALID_DIAGNOSTIC : 0u;
             if ((rc = mark(ctx, TAG_ORIGIN, st, lane))) break;
             if (ctx->svd_method == 0)
                 rc = debug ? launch_svd<true>(ctx, cm, dq, cn, o, st, lane) : launch_svd<false>(ctx, cm, dq, cn, o, st, lane);
@@ -799,12 +817,23 @@ int ensure_streams(tq_ctx *ctx)
     return TQ_OK;
 }
 
+// called before a device-API entry point enqueues work that touches the shared scratch (count slab, ordering and
+// singular-value scratch, replicate layout): if the previous device-API call went to ANOTHER stream, this stream is
+// made to wait for it -- two device-API calls of one context are ordered in call order whatever their streams
+int enter_dev_api(tq_ctx *ctx, hipStream_t stream)
+{
+    if (ctx->dev_api_pending && ctx->evDevApi && stream != ctx->last_dev_stream)
+        TQ_HIP(ctx, hipStreamWaitEvent(stream, ctx->evDevApi, 0));
+    return TQ_OK;
+}
+
 // called after a device-API entry point has enqueued work on the caller's stream
 int note_dev_api(tq_ctx *ctx, hipStream_t stream, int rc)
 {
     if (!ctx->evDevApi) TQ_HIP(ctx, hipEventCreateWithFlags(&ctx->evDevApi, hipEventDisableTiming));
     TQ_HIP(ctx, hipEventRecord(ctx->evDevApi, stream));
     ctx->dev_api_pending = true;
+    ctx->last_dev_stream = stream;
     return rc;
 }
 
@@ -1145,6 +1174,7 @@ int tq_resolve_dev(tq_ctx *ctx, const uint32_t *d_quartets, int64_t Q, int subsa
         return fail(ctx, TQ_ERR_INVALID_ARG, "tq_resolve_dev: NULL pointer or negative Q");
     TQ_HIP(ctx, hipSetDevice(ctx->device));
     OutPtrs out{d_rstat, d_rscor, d_flags, nullptr, nullptr, nullptr};
+    if (int rc = enter_dev_api(ctx, (hipStream_t)stream)) return rc;
     return note_dev_api(ctx, (hipStream_t)stream,
                         launch(ctx, d_quartets, Q, subsample, false, false, out, (hipStream_t)stream, NoChunkHook()));
 }
@@ -1160,6 +1190,7 @@ int tq_scan_dev(tq_ctx *ctx, const uint32_t *d_quartets, int64_t Q, int subsampl
     if (rc) return rc;
     TQ_HIP(ctx, hipSetDevice(ctx->device));
     if (ctx->timing) ctx->timed_calls++;
+    if ((rc = enter_dev_api(ctx, (hipStream_t)stream))) return rc;
     return note_dev_api(ctx, (hipStream_t)stream, stage_scan(ctx, d_quartets, Q, subsample, false, (hipStream_t)stream));
 }
 
@@ -1172,6 +1203,7 @@ int tq_svd_dev(tq_ctx *ctx, int64_t q0, int64_t n, uint32_t *d_rstat, double *d_
     if (n == 0) return TQ_OK;
     TQ_HIP(ctx, hipSetDevice(ctx->device));
     OutPtrs out{d_rstat, d_rscor, d_flags, nullptr, nullptr, nullptr};
+    if (int rc = enter_dev_api(ctx, (hipStream_t)stream)) return rc;
     return note_dev_api(ctx, (hipStream_t)stream, stage_svd(ctx, q0, n, false, out, (hipStream_t)stream, NoChunkHook()));
 }
 
@@ -1214,6 +1246,7 @@ int tq_resolve_range_dev(tq_ctx *ctx, uint64_t first_rank, int64_t Q, int subsam
     TQ_HIP(ctx, hipGetLastError());
     OutPtrs out{d_rstat, d_rscor, d_flags, nullptr, nullptr, nullptr};
     // consecutive lexicographic ranks are in (a,b,c) order already
+    if (int rc2 = enter_dev_api(ctx, (hipStream_t)stream)) return rc2;
     return note_dev_api(ctx, (hipStream_t)stream,
                         launch(ctx, dq, Q, subsample, false, true, out, (hipStream_t)stream, NoChunkHook()));
 }
@@ -1305,7 +1338,7 @@ int tq_resolve_debug(tq_ctx *ctx, const uint32_t *quartets, int64_t Q, int subsa
         (void)hipStreamSynchronize(ctx->sK);
         return rc;
     }
-    OutPtrs out;
+    OutPtrs out{};
     out.rstat = (uint32_t *)(base + o_rstat);
     out.rscor = (double *)(base + o_rscor);
     out.flags = (uint8_t *)(base + o_flags);
@@ -1466,6 +1499,7 @@ int tq_set_option(tq_ctx *ctx, const char *name, int64_t value)
     }
     if (!strcmp(name, "batch")) {
         if (value < 0) return fail(ctx, TQ_ERR_INVALID_ARG, "batch must be >= 0");
+        if (value > 0x7FFFFFFFll) value = 0x7FFFFFFFll;      // item counts reach hipCUB as int
         ctx->batch = value ? value : (1 << 23);
         return TQ_OK;
     }
@@ -1533,6 +1567,7 @@ int tq_bootstrap_async(tq_ctx *ctx, const int64_t *lidxs, int64_t n, uint64_t se
         S += ctx->h_spans[2 * lidxs[i] + 1] - ctx->h_spans[2 * lidxs[i]];
     }
     TQ_HIP(ctx, hipSetDevice(ctx->device));
+    if (int rc0 = enter_dev_api(ctx, stream)) return rc0;      // a resolve still scanning the previous replicate on another stream
     const int64_t T = ctx->src_T;
     // worst-case replicate length; buffers grow only
     const int64_t cap = n * ctx->max_width;

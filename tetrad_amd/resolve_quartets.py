@@ -17,7 +17,7 @@ from pathlib import Path
 
 import numpy as np
 
-from ._lib import FLAG_NO_CONVERGENCE
+from ._lib import FLAG_INVALID_DIAGNOSTIC, FLAG_NO_CONVERGENCE
 from .engine import QuartetEngine
 
 _engines: dict[int, QuartetEngine] = {}
@@ -80,6 +80,9 @@ def new_infer_resolved_quartets(tmparr, tmpmap, quartets, subsample_snps, device
     rstat, rscor, flags = eng.resolve(quartets, subsample_snps)
     if (flags & FLAG_NO_CONVERGENCE).any():                       # np.linalg.svd raises the same (:242)
         raise np.linalg.LinAlgError("SVD did not converge")
+    if (flags & FLAG_INVALID_DIAGNOSTIC).any():
+        raise RuntimeError("the engine is in a timing-diagnostic mode (scan_method 2..5 or phases 1 / 2): its rows are "
+                           "not results; reset the option before resolving")
     return quartets, rstat, rscor
 
 

@@ -353,6 +353,10 @@ def launch_ranks(args, argv) -> int:
                              f"(use --backend gloo to rehearse the {n}-rank control flow on fewer GPUs)\n")
             return 2
     env = dict(os.environ)
+    # RCCL opens peers' buffers through HIP IPC handles.  The hosts of this pool support only dmabuf IPC: with the legacy
+    # mode (the runtime's default) hipIpcGetMemHandle fails with "invalid argument" and the communicator cannot be
+    # built.  The image exports the variable already (build environment notes); it is repeated here -- never overriding a
+    # value the caller set -- because a rank started from a scrubbed environment would fail in exactly that way.
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                TQ_BENCH_SELF_LAUNCHED="1")

@@ -22,7 +22,7 @@ def load_golden(name):
 
 GOLDEN_FULL_CASES = [
     "dense_T8_S400", "tree_T12_S2000", "sparse_T10_S257", "edge_T7_S130",
-    "carry_T6_S2500", "tiny_T5_S37", "one_site_T5_S1", "lowrank_T9_S700",
+    "carry_T6_S2500", "tiny_T5_S37", "one_site_T5_S1", "lowrank_T9_S700", "minrank_T14_S600",
 ]
 
 

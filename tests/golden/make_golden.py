@@ -108,8 +108,12 @@ def loci_map(S, rng, mean=4):
     return tmap
 
 
-def main():
+def main(only=None):
     ref = load_reference()
+    if only == "minrank_T14_S600":          # (11) alone: the other fixtures are unchanged (they reproduce bit for bit)
+        arr, tmap = synth.simulate_tmparr(14, 600, seed=9, p=0.01, missing=0.3)
+        save("minrank_T14_S600", arr, tmap, synth.all_quartets(14), ref)
+        return
 
     # (1) dense uniform-random data, T=8, S=400 (S not a multiple of 64), all 70 quartets
     rng = np.random.default_rng(1)
@@ -155,6 +159,13 @@ def main():
     arr = (rng.random((9, 700)) < 0.5).astype(np.uint8) * 2     # only A / G
     arr[rng.random(arr.shape) < 0.05] = 78
     save("lowrank_T9_S700", arr, loci_map(700, rng), synth.all_quartets(9), ref)
+
+    # (11) the minrank < 10 branch (resolve_quartets.py:246) on rows whose argmin is NOT decided by rounding noise:
+    #      sparse tree-like data, 14 taxa, all 1001 quartets -- 776 (full) / 853 (subsample) rows with a numerical rank
+    #      below 10 and the two lowest scores well apart (sparse_T10_S257 has 377; lowrank_T9_S700 none: all of its rows are
+    #      within 1e-9 * sigma_max in the reference itself)
+    arr, tmap = synth.simulate_tmparr(14, 600, seed=9, p=0.01, missing=0.3)
+    save("minrank_T14_S600", arr, tmap, synth.all_quartets(14), ref)
 
     # (9) config c1: 16 taxa, 5k SNPs, all 1820 quartets (BASELINE.json configs[0]).
     arr, tmap, qrts = synth.make_config("c1")
@@ -254,6 +265,8 @@ if __name__ == "__main__":
     which = sys.argv[1:] or ["main", "resample", "c5"]
     if "main" in which:
         main()
+    if "minrank" in which:
+        main(only="minrank_T14_S600")
     if "resample" in which:
         make_resample_golden()
     if "c5" in which:

@@ -168,3 +168,60 @@ def test_two_rank_gloo_gather_equals_single_rank(tmp_path, oracle):
     first = rows[0].split("\t")
     assert len(first) == 9 and [int(x) for x in first[:4]] == g["quartets"][0].tolist()
     assert rows[-1].split("\t")[7] == str(int(rstat[100, 0]))
+
+
+SKEW_WORKER = r'''
+import os, sys, time
+import numpy as np
+sys.path.insert(0, sys.argv[1])
+import torch.distributed as dist
+from oracle import oracle as orc
+from tetrad_amd import distributor as D
+rank, world, port, out = int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], sys.argv[5]
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=port, RANK=str(rank), WORLD_SIZE=str(world))
+dist.init_process_group("gloo", rank=rank, world_size=world)
+g = np.load(os.path.join(sys.argv[1], "tests", "golden", "tree_T12_S2000.npz"))
+calls = []
+def compute(tmparr, tmpmap, q, sub):
+    t0 = time.perf_counter()
+    _, rstat, rscor, dbg = orc.new_infer_resolved_quartets(tmparr, tmpmap, q, sub, debug=True)
+    if rank == 1:                                  # this rank's compute step takes three times as long
+        time.sleep(2.0 * (time.perf_counter() - t0) + 0.05)
+    calls.append(len(q))
+    return rstat, rscor, dbg["flags"]
+qr = g["quartets"][:157]
+res = {}
+for step in range(3):                              # several steps back to back: a slow rank must not let pieces of
+    for pieces in (1, 4):                          # different steps or different pieces overtake each other
+        _, rstat, rscor, flags = D.resolve_sharded(g["tmparr"], g["tmpmap"], qr, bool(step & 1), compute=compute, pieces=pieces)
+        res[f"rstat_{step}_{pieces}"] = rstat
+        res[f"rscor_{step}_{pieces}"] = rscor
+np.savez(out + f".{rank}.npz", calls=np.array(calls), **res)
+dist.barrier()
+dist.destroy_process_group()
+'''
+
+
+def test_two_rank_gather_with_one_rank_three_times_slower(tmp_path, oracle):
+    """Skewed per-rank cost (SURVEY 8e: 'optionally finer-grained tiles if per-quartet cost varies'): the partition is
+    static, so a slow rank stretches the step -- but the piece pipeline must neither deadlock nor reorder: every rank
+    ends with exactly the one-rank rows, for one piece and for four, over several consecutive steps in both modes."""
+    import subprocess
+    script = tmp_path / "skew_worker.py"
+    script.write_text(SKEW_WORKER)
+    port, out = _free_port(), str(tmp_path / "skew")
+    procs = [subprocess.Popen([sys.executable, str(script), str(REPO), str(r), "2", port, out]) for r in range(2)]
+    for p in procs:
+        assert p.wait(timeout=600) == 0
+    g = load_golden("tree_T12_S2000")
+    want = {}
+    for sub in (False, True):
+        _, rstat, rscor = oracle.new_infer_resolved_quartets(g["tmparr"], g["tmpmap"], g["quartets"][:157], sub)
+        want[sub] = (rstat, rscor)
+    for r in range(2):
+        z = np.load(out + f".{r}.npz")
+        for step in range(3):
+            for pieces in (1, 4):
+                np.testing.assert_array_equal(z[f"rstat_{step}_{pieces}"], want[bool(step & 1)][0])
+                np.testing.assert_array_equal(z[f"rscor_{step}_{pieces}"], want[bool(step & 1)][1])
+        assert z["calls"].sum() > 0

@@ -117,3 +117,17 @@ def test_oracle_matches_reference_on_c5_replicate(oracle):
         np.testing.assert_array_equal(dbg["cmats"], g[f"{mode}_cmats"])
         np.testing.assert_array_equal(rstat, g[f"{mode}_rstat"])
         np.testing.assert_array_equal(rscor, g[f"{mode}_rscor"])
+
+
+def test_minrank_fixture_covers_the_low_rank_branch_with_decided_rows():
+    """What `minrank_T14_S600` is there for: resolve_quartets.py:246 takes `minrank = min(10, rank.min())`; the fixture
+    must hold many rows whose numerical rank is below 10 AND whose two lowest reference scores are well apart (so that
+    the topology comparison on them means something) -- counted from the reference's own singular values."""
+    g = load_golden("minrank_T14_S600")
+    for mode, at_least in (("full", 700), ("sub", 800)):
+        sv, rscor, zero = g[f"{mode}_svds"], g[f"{mode}_rscor"], g[f"{mode}_zero_data"]
+        rank = (sv > sv.max(axis=2, keepdims=True) * 16 * np.finfo(float).eps).sum(axis=2).min(axis=1)
+        s = np.sort(rscor, axis=1)
+        decided = (s[:, 1] - s[:, 0]) > 2e-9 * sv.max(axis=(1, 2))
+        n = int(((rank < 10) & decided & ~zero).sum())
+        assert n >= at_least, (mode, n)

@@ -230,6 +230,13 @@ int tq_set_option(tq_ctx *ctx, const char *name, int64_t value);
  * of option bdsqr_stats.  No reference counterpart.                                                                    */
 int tq_debug_fetch(tq_ctx *ctx, int which, void *dst, int64_t bytes);
 
+/* Test hook: run the bidiagonal-QR kernel (tq_bdsqr_kernel) alone on nmat bidiagonals given on the host -- de f64[nmat][32]
+ * as tq_debug_fetch(which = 1) hands them out, in ANY order: lane i of wave w gets matrix 64 w + i -- and return the singular
+ * values sv f64[nmat][16] (unsorted; may be NULL), per matrix its rotation steps | sweeps << 16 (work u32[nmat]; may be NULL)
+ * and the mean duration of `reps` launches in ms.  Used to measure what ordering the matrices into waves is worth
+ * (tools/bdsqr_order.py).  No reference counterpart.                                                                */
+int tq_debug_bdsqr(tq_ctx *ctx, const double *de, int64_t nmat, double *sv, uint32_t *work, int reps, double *ms);
+
 /* Text for the consumers right after the hot path (host code, no device involved).
  * tq_format_tsv writes the rows the reference appends to <name>.quartets_<rep>.tsv
  *   (run_inference.py:233-234: pd.concat([rqrts, rscor, rstat], axis=1).to_csv(sep="\t",

@@ -32,7 +32,7 @@ SYMBOLS = [
     "tq_host_alloc", "tq_host_free", "tq_resolve_to_host", "tq_scan_dev", "tq_svd_dev",
     "tq_resolve_dev", "tq_resolve_range_dev", "tq_unrank_dev", "tq_resolve_debug",
     "tq_timing_enable", "tq_timing_read", "tq_timing_read_split", "tq_timing_read_kernels",
-    "tq_set_option", "tq_device_info", "tq_debug_fetch",
+    "tq_set_option", "tq_device_info", "tq_debug_fetch", "tq_debug_bdsqr",
     "tq_format_tsv", "tq_format_qmc", "tq_qmc_tree", "tq_qmc_splits", "tq_unrank", "tq_numpy_choice_tail",
 ]
 
@@ -154,6 +154,8 @@ def load() -> ctypes.CDLL:
     lib.tq_timing_read_split.restype = i32
     lib.tq_debug_fetch.argtypes = [vp, i32, vp, i64]
     lib.tq_debug_fetch.restype = i32
+    lib.tq_debug_bdsqr.argtypes = [vp, vp, i64, vp, vp, i32, c.POINTER(c.c_double)]
+    lib.tq_debug_bdsqr.restype = i32
     lib.tq_set_option.argtypes = [vp, c.c_char_p, i64]
     lib.tq_set_option.restype = i32
     lib.tq_format_tsv.argtypes = [vp, vp, vp, i64, vp, i64, c.POINTER(i64)]

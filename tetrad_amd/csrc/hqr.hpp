@@ -62,7 +62,7 @@ __device__ __forceinline__ double sqrt_nr(double x)     // x >= 0, full precisio
 template <bool DEBUG>
 __global__ void __launch_bounds__(WAVE, 2)
 tq_bidiag_kernel(const uint32_t *__restrict__ cm, int64_t Q, double *__restrict__ de,
-                 uint32_t *__restrict__ nsnps_out, uint32_t *__restrict__ cmats_dbg)
+                 uint32_t *__restrict__ nsnps_out, uint32_t *__restrict__ cmats_dbg, int tsplit)
 {
     constexpr int QP = 16;                       // quartets per wave pass (one per quad)
     // a quartet's 256 counts sit 260 dwords apart: the 16 quads read the same bin of 16 different quartets in every
@@ -75,8 +75,14 @@ tq_bidiag_kernel(const uint32_t *__restrict__ cm, int64_t Q, double *__restrict_
     const int quad = lane >> 2;
     const int c = lane & 3;
 
+    // tsplit = 1 (small batches): the three flattenings of a pass go to three blocks instead of one after the other --
+    // a call of a few thousand quartets (the reference's chunk sizes, run_inference.py:73-96) does not fill the chip
+    // and is bound by the latency of its kernels: 33 -> 13 us for 1 000 quartets.  Same arithmetic per matrix.
     const int64_t npass = (Q + QP - 1) / QP;
-    for (int64_t wg = blockIdx.x; wg < npass; wg += gridDim.x) {
+    const int64_t nitem = tsplit ? 3 * npass : npass;
+    for (int64_t item = blockIdx.x; item < nitem; item += gridDim.x) {
+        const int64_t wg = tsplit ? item / 3 : item;
+        const int t_lo = tsplit ? (int)(item - 3 * wg) : 0, t_hi = tsplit ? t_lo + 1 : 3;
         const int64_t q0 = wg * QP;
         {
             const uint4 *src = reinterpret_cast<const uint4 *>(cm + q0 * 256);
@@ -98,11 +104,11 @@ tq_bidiag_kernel(const uint32_t *__restrict__ cm, int64_t Q, double *__restrict_
             for (int k = 0; k < 64; ++k) s += cmq[4 * k + c];
             s += __shfl_xor(s, 1, WAVE);
             s += __shfl_xor(s, 2, WAVE);
-            if (c == 0 && myq < Q) nsnps_out[myq] = s;
+            if (c == 0 && myq < Q && t_lo == 0) nsnps_out[myq] = s;
         }
-        double thr2 = 0.0;                                      // set at t = 0: ||M_t||_F is the same for all three
+        double thr2 = 0.0;                                      // set at the first t: ||M_t||_F is the same for all three
 #pragma unroll 1
-        for (int t = 0; t < 3; ++t) {
+        for (int t = t_lo; t < t_hi; ++t) {
             double a[4][16];                                    // a[s][r] = M_t[r][4s + c]
             // bin of M_t[r][4s + c], r = 4 rh + rl: 64 rh + RL rl + SS s + CS c with (RL, SS, CS) = (16, 4, 1), (4, 16, 1),
             // (1, 16, 4) for t = 0, 1, 2 (flat_bin).  t is a runtime (scalar) value, so the three strides are SGPRs: 16
@@ -133,8 +139,9 @@ tq_bidiag_kernel(const uint32_t *__restrict__ cm, int64_t Q, double *__restrict_
             // (~1e-17) is "reflected", the next one shrinks to ~1e-33, ... and after ten such
             // columns the squared norms reach the denormal range, 1/den overflows and the rest of
             // the matrix is destroyed (found by the sparse-data stress test against the Jacobi path).
-            // (the three flattenings hold the same 256 counts, so their Frobenius norms agree: once per quartet)
-            if (t == 0) {
+            // (the three flattenings hold the same 256 counts, so their Frobenius norms agree -- exactly: the squares
+            // are integers below 2^53, every summation order gives the same double: once per quartet)
+            if (t == t_lo) {
                 double f2 = 0.0;
 #pragma unroll
                 for (int s = 0; s < 4; ++s) {
@@ -235,7 +242,7 @@ constexpr int RSQ_NR = 1;      // Newton steps on v_rsq_f64 inside a rotation (1
 
 __global__ void __launch_bounds__(WAVE)
 tq_bdsqr_kernel(const double *__restrict__ de, int64_t nmat, double *__restrict__ sv, int maxit,
-                unsigned long long *__restrict__ stats)
+                unsigned long long *__restrict__ stats, uint32_t *__restrict__ work_out = nullptr)
 {
     __shared__ double lds[32 * WAVE];
     const int lane = threadIdx.x;
@@ -347,6 +354,10 @@ tq_bdsqr_kernel(const double *__restrict__ de, int64_t nmat, double *__restrict_
             // current step's arithmetic, each hypot shares one rsq with the reciprocal its rotation
             // needs, and a zero pivot is a select, not a branch (f = h = 0 there, so c = s = 0 * rz)
             double gn = E_(l + 1), yn = W_(l + 1);
+            if (work_out) {
+                my_steps += (uint32_t)(nm - l + 1);
+                ++my_sweeps;
+            }
             if (stats) {
                 my_steps += (uint32_t)(nm - l + 1);
                 ++my_sweeps;
@@ -389,6 +400,7 @@ tq_bdsqr_kernel(const double *__restrict__ de, int64_t nmat, double *__restrict_
         }
 #undef SET_E
 #undef SET_W
+        if (work_out && live) work_out[m] = my_steps | (my_sweeps << 16);     // test hook (tq_debug_bdsqr): this matrix's work
         if (stats) {
             // a lane takes part in every sweep of the wave until its own matrix is done, so its wave_iters is what
             // the wave had issued when it finished; the maximum over the lanes is what the wave issued in all

@@ -641,9 +641,10 @@ int launch_hqr(tq_ctx *ctx, const uint32_t *cm, const uint32_t *dq, int64_t n, c
     // one pass per block unless told otherwise: the work per pass varies (QR iterations), and the
     // hardware dispatcher balances it better than a static grid-stride loop (3.8 ms vs 5.1 ms per 1e6)
     const int svd_wpc = ctx->svd_wpc > 0 ? ctx->svd_wpc : (1 << 20);
-    int rc = grid_for(ctx, k1, (n + 15) / 16, &grid, svd_wpc);
+    const int tsplit = n < 32768 ? 1 : 0;          // small batches: one block per (pass, flattening), tq_bidiag_kernel
+    int rc = grid_for(ctx, k1, (tsplit ? 3 : 1) * ((n + 15) / 16), &grid, svd_wpc);
     if (rc) return rc;
-    hipLaunchKernelGGL(k1, dim3((unsigned)grid), dim3(WAVE), 0, stream, cm, n, de, nsnps, out.cmats);
+    hipLaunchKernelGGL(k1, dim3((unsigned)grid), dim3(WAVE), 0, stream, cm, n, de, nsnps, out.cmats, tsplit);
     TQ_HIP(ctx, hipGetLastError());
     if ((rc = mark(ctx, TAG_BIDIAG, stream, lane))) return rc;
     const int64_t nmat = 3 * n;
@@ -1718,6 +1719,49 @@ int tq_debug_fetch(tq_ctx *ctx, int which, void *dst, int64_t bytes)
     TQ_HIP(ctx, hipDeviceSynchronize());
     TQ_HIP(ctx, hipMemcpy(dst, src, (size_t)bytes, hipMemcpyDeviceToHost));
     return TQ_OK;
+}
+
+int tq_debug_bdsqr(tq_ctx *ctx, const double *de, int64_t nmat, double *sv, uint32_t *work, int reps, double *ms)
+{
+    if (!ctx || !de || nmat < 1 || reps < 1) return TQ_ERR_INVALID_ARG;
+    TQ_HIP(ctx, hipSetDevice(ctx->device));
+    double *d_de = nullptr, *d_sv = nullptr;
+    uint32_t *d_work = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    int rc = TQ_OK;
+    auto step = [&](hipError_t e, const char *what) {
+        if (!rc && e != hipSuccess) rc = fail(ctx, e == hipErrorOutOfMemory ? TQ_ERR_OOM : TQ_ERR_HIP, "tq_debug_bdsqr: %s: %s", what, hipGetErrorString(e));
+    };
+    step(hipMalloc(&d_de, (size_t)nmat * 256), "hipMalloc");
+    if (!rc) step(hipMalloc(&d_sv, (size_t)nmat * 128), "hipMalloc");
+    if (!rc) step(hipMalloc(&d_work, (size_t)nmat * 4), "hipMalloc");
+    if (!rc) step(hipMemcpy(d_de, de, (size_t)nmat * 256, hipMemcpyHostToDevice), "H2D");
+    if (!rc) step(hipEventCreate(&e0), "event");
+    if (!rc) step(hipEventCreate(&e1), "event");
+    const unsigned grid = (unsigned)((nmat + WAVE - 1) / WAVE);
+    if (!rc) {
+        // once with the per-matrix counters (slower), then `reps` timed launches of the product form
+        hipLaunchKernelGGL(tq_bdsqr_kernel, dim3(grid), dim3(WAVE), 0, 0, (const double *)d_de, nmat, d_sv, ctx->bdsqr_maxit,
+                           (unsigned long long *)nullptr, d_work);
+        step(hipGetLastError(), "launch");
+        if (!rc) step(hipEventRecord(e0, 0), "record");
+        for (int i = 0; i < reps && !rc; ++i)
+            hipLaunchKernelGGL(tq_bdsqr_kernel, dim3(grid), dim3(WAVE), 0, 0, (const double *)d_de, nmat, d_sv, ctx->bdsqr_maxit,
+                               (unsigned long long *)nullptr, (uint32_t *)nullptr);
+        if (!rc) step(hipEventRecord(e1, 0), "record");
+        if (!rc) step(hipEventSynchronize(e1), "sync");
+        float t = 0.f;
+        if (!rc) step(hipEventElapsedTime(&t, e0, e1), "elapsed");
+        if (ms) *ms = (double)t / reps;
+    }
+    if (!rc && sv) step(hipMemcpy(sv, d_sv, (size_t)nmat * 128, hipMemcpyDeviceToHost), "D2H");
+    if (!rc && work) step(hipMemcpy(work, d_work, (size_t)nmat * 4, hipMemcpyDeviceToHost), "D2H");
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    if (d_de) (void)hipFree(d_de);
+    if (d_sv) (void)hipFree(d_sv);
+    if (d_work) (void)hipFree(d_work);
+    return rc;
 }
 
 int tq_format_tsv(const uint32_t *quartets, const uint32_t *rstat, const double *rscor, int64_t Q, char *out,

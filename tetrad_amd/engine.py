@@ -252,6 +252,17 @@ class QuartetEngine:
         self._check(self._lib.tq_debug_fetch(self._h, code, _ptr(out), out.nbytes))
         return out
 
+    def debug_bdsqr(self, de: np.ndarray, reps: int = 5):
+        """Test hook: the bidiagonal-QR kernel alone on `de` f64[nmat,32] in the given order ->
+        (sv f64[nmat,16], rotation steps u32[nmat], sweeps u32[nmat], ms per launch)."""
+        de = np.ascontiguousarray(de, dtype=np.float64)
+        nmat = de.shape[0]
+        sv = np.zeros((nmat, 16), np.float64)
+        work = np.zeros(nmat, np.uint32)
+        ms = ctypes.c_double()
+        self._check(self._lib.tq_debug_bdsqr(self._h, _ptr(de), nmat, _ptr(sv), _ptr(work), reps, ctypes.byref(ms)))
+        return sv, work & 0xFFFF, work >> 16, ms.value
+
     def device_info(self):
         cu = ctypes.c_int32()
         w = ctypes.c_int32()

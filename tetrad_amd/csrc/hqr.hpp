@@ -232,6 +232,192 @@ tq_bidiag_kernel(const uint32_t *__restrict__ cm, int64_t Q, double *__restrict_
     }
 }
 
+// ------------------------------------------------------------------------------------
+// tq_bidiag2_kernel: the same bidiagonalisation with the matrix dealt 2 x 2 over the quad: lane (ri, ci) = 2 ri + ci of a
+// quad holds the rows of parity ri and the columns of parity ci (8 x 8 values, a[cs][rs] = M[2 rs + ri][2 cs + ci]).
+// In the column layout of tq_bidiag_kernel a left reflector's vector lives in ONE lane (16 - K broadcasts, two DPP moves
+// each -- 64-bit DPP does not exist) and every row of a right reflector is summed over all FOUR lanes (two butterflies);
+// here both reflectors cost one broadcast per value a lane needs (8 - K/2) and one one-stage butterfly per dot product:
+// ~520 instead of ~840 v_mov_b32_dpp and ~130 instead of ~270 butterfly adds per matrix.  Mod-2 interleaving keeps all
+// four lanes busy while the active block shrinks.  Same reflectors, same thresholds, same outputs (d, e, nsnps).
+// ------------------------------------------------------------------------------------
+template <int SRC_CI>
+__device__ __forceinline__ double quad_from_ci(double v)          // value of the lane with the same ri and ci = SRC_CI
+{
+    constexpr int CTRL = SRC_CI | (SRC_CI << 2) | ((2 + SRC_CI) << 4) | ((2 + SRC_CI) << 6);
+    const int lo = dpp_mov<CTRL>(__double2loint(v));
+    const int hi = dpp_mov<CTRL>(__double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
+
+template <int SRC_RI>
+__device__ __forceinline__ double quad_from_ri(double v)          // value of the lane with the same ci and ri = SRC_RI
+{
+    constexpr int CTRL = (2 * SRC_RI) | ((2 * SRC_RI + 1) << 2) | ((2 * SRC_RI) << 4) | ((2 * SRC_RI + 1) << 6);
+    const int lo = dpp_mov<CTRL>(__double2loint(v));
+    const int hi = dpp_mov<CTRL>(__double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
+
+template <bool DEBUG>
+__global__ void __launch_bounds__(WAVE, 2)
+tq_bidiag2_kernel(const uint32_t *__restrict__ cm, int64_t Q, double *__restrict__ de,
+                  uint32_t *__restrict__ nsnps_out, uint32_t *__restrict__ cmats_dbg, int tsplit)
+{
+    constexpr int QP = 16;
+    constexpr int QPITCH = 260;
+    __shared__ uint32_t lds[QP * QPITCH];
+    const int lane = threadIdx.x;
+    const int quad = lane >> 2;
+    const int ri = (lane >> 1) & 1, ci = lane & 1;
+
+    const int64_t npass = (Q + QP - 1) / QP;
+    const int64_t nitem = tsplit ? 3 * npass : npass;
+    for (int64_t item = blockIdx.x; item < nitem; item += gridDim.x) {
+        const int64_t wg = tsplit ? item / 3 : item;
+        const int t_lo = tsplit ? (int)(item - 3 * wg) : 0, t_hi = tsplit ? t_lo + 1 : 3;
+        const int64_t q0 = wg * QP;
+        {
+            const uint4 *src = reinterpret_cast<const uint4 *>(cm + q0 * 256);
+            uint4 *dst = reinterpret_cast<uint4 *>(lds);
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const int idx = lane + WAVE * k;
+                const bool ok = (q0 + k) < Q;
+                dst[k * (QPITCH / 4) + lane] = ok ? src[idx] : make_uint4(0, 0, 0, 0);
+            }
+        }
+        __syncthreads();
+        const int64_t myq = q0 + quad;
+        const uint32_t *cmq = lds + QPITCH * quad;
+        {
+            uint32_t s = 0;
+            const int c4 = lane & 3;
+#pragma unroll
+            for (int k = 0; k < 64; ++k) s += cmq[4 * k + c4];
+            s += __shfl_xor(s, 1, WAVE);
+            s += __shfl_xor(s, 2, WAVE);
+            if (c4 == 0 && myq < Q && t_lo == 0) nsnps_out[myq] = s;
+        }
+        double thr2 = 0.0;
+#pragma unroll 1
+        for (int t = t_lo; t < t_hi; ++t) {
+            double a[8][8];                                     // a[cs][rs] = M_t[2 rs + ri][2 cs + ci]
+            // bin of M_t[r][col], r = 4 rh + rl, col = 4 s + c: 64 rh + RL rl + SS s + CS c (see tq_bidiag_kernel); with
+            // r = 2 rs + ri, col = 2 cs + ci: rh = rs >> 1, rl = 2 (rs & 1) + ri, s = cs >> 1, c = 2 (cs & 1) + ci
+            {
+                const int RL = t == 0 ? 16 : (t == 1 ? 4 : 1), SS = t == 0 ? 4 : 16, CS = t == 2 ? 4 : 1;
+                const uint32_t *base = cmq + RL * ri + CS * ci;
+#pragma unroll
+                for (int cs = 0; cs < 8; ++cs) {
+#pragma unroll
+                    for (int rlo = 0; rlo < 2; ++rlo) {
+                        const uint32_t *pp = base + 2 * RL * rlo + SS * (cs >> 1) + 2 * CS * (cs & 1);
+#pragma unroll
+                        for (int rh = 0; rh < 4; ++rh) {
+                            const int rs = 2 * rh + rlo;
+                            const uint32_t v = pp[64 * rh];
+                            a[cs][rs] = (double)v;
+                            if (DEBUG) {
+                                if (cmats_dbg && myq < Q)
+                                    cmats_dbg[((myq * 3 + t) * 16 + 2 * rs + ri) * 16 + 2 * cs + ci] = v;
+                            }
+                        }
+                    }
+                }
+            }
+            if (t == t_lo) {
+                double f2 = 0.0;
+#pragma unroll
+                for (int cs = 0; cs < 8; ++cs) {
+#pragma unroll
+                    for (int rs = 0; rs < 8; ++rs) f2 = fma(a[cs][rs], a[cs][rs], f2);
+                }
+                thr2 = quad_sum(f2) * 1e-40;
+            }
+            double *dout = de + (myq * 3 + t) * 32;
+            const bool writer = ((lane & 3) == 0) && (myq < Q);
+            if (writer) dout[16] = 0.0;
+            static_for<0, 16>([&](auto kc) {
+                constexpr int K = decltype(kc)::value;
+                constexpr int PK = K & 1, S0 = K >> 1;           // row / column K: parity PK, slot S0
+                // ---- left reflector: zero column K below the diagonal ----
+                {
+                    // column K's values of this lane's rows: from the lane of the same row parity that holds column K
+                    double v[8];
+#pragma unroll
+                    for (int rs = S0; rs < 8; ++rs) v[rs] = quad_from_ci<PK>(a[S0][rs]);
+                    if constexpr (PK == 1) v[S0] = (ri == 1) ? v[S0] : 0.0;     // row 2 S0 = K - 1 is above the diagonal
+                    double n2 = 0.0;
+#pragma unroll
+                    for (int rs = S0; rs < 8; ++rs) n2 = fma(v[rs], v[rs], n2);
+                    n2 += dpx<2>(n2);                                        // + the rows of the other parity
+                    const bool live = n2 > thr2;
+                    const double nrm = sqrt_nr(n2);
+                    const double x0 = quad_from_ri<PK>(v[S0]);               // M[K][K]
+                    const double alpha = live ? ((x0 < 0.0) ? nrm : -nrm) : 0.0;
+                    if (ri == PK) v[S0] = x0 - alpha;
+                    const double den = fma(-alpha, x0, n2);
+                    const double beta = live ? rcp_nr<1>(den) : 0.0;
+                    if (writer) dout[K] = alpha;
+                    // columns right of K: slot S0 holds column K + 1 for the lanes with ci = 1 when K is even
+                    constexpr int CS0 = PK == 0 ? S0 : S0 + 1;
+#pragma unroll
+                    for (int cs = CS0; cs < 8; ++cs) {
+                        double w = 0.0;
+#pragma unroll
+                        for (int rs = S0; rs < 8; ++rs) w = fma(v[rs], a[cs][rs], w);
+                        w += dpx<2>(w);
+                        w *= beta;
+                        if (cs == S0) w = (ci == 1) ? w : 0.0;               // K even: column K itself is finished
+#pragma unroll
+                        for (int rs = S0; rs < 8; ++rs) a[cs][rs] = fma(-w, v[rs], a[cs][rs]);
+                    }
+                }
+                // ---- right reflector: zero row K right of the superdiagonal ----
+                if constexpr (K <= 13) {
+                    constexpr int K1 = K + 1, P1 = K1 & 1, S1 = K1 >> 1;
+                    // row K's values of this lane's columns: from the lane of the same column parity that holds row K
+                    double y[8];
+                    double p = 0.0;
+#pragma unroll
+                    for (int cs = S1; cs < 8; ++cs) y[cs] = quad_from_ri<PK>(a[cs][S0]);
+                    if constexpr (P1 == 1) y[S1] = (ci == 1) ? y[S1] : 0.0;     // column 2 S1 = K is the diagonal
+#pragma unroll
+                    for (int cs = S1; cs < 8; ++cs) p = fma(y[cs], y[cs], p);
+                    const double n2 = p + dpx<1>(p);
+                    const bool live = n2 > thr2;
+                    const double x0 = quad_from_ci<P1>(y[S1]);               // M[K][K + 1]
+                    const double nrm = sqrt_nr(n2);
+                    const double alpha = live ? ((x0 < 0.0) ? nrm : -nrm) : 0.0;
+                    const double den = fma(-alpha, x0, n2);
+                    const double beta = live ? rcp_nr<1>(den) : 0.0;
+                    if (ci == P1) y[S1] = x0 - alpha;
+                    if (writer) dout[16 + K1] = alpha;
+                    double yb[8];
+#pragma unroll
+                    for (int cs = S1; cs < 8; ++cs) yb[cs] = -beta * y[cs];
+                    // rows below K: slot S1 holds row K + 1 for the lanes with ri = 1 when K + 1 is odd (its ri = 0 row is K)
+#pragma unroll
+                    for (int rs = S1; rs < 8; ++rs) {
+                        double q = 0.0;
+#pragma unroll
+                        for (int cs = S1; cs < 8; ++cs) q = fma(yb[cs], a[cs][rs], q);
+                        double tt = q + dpx<1>(q);                           // = -beta * (row . y)
+                        if (P1 == 1 && rs == S1) tt = (ri == 1) ? tt : 0.0;
+#pragma unroll
+                        for (int cs = S1; cs < 8; ++cs) a[cs][rs] = fma(tt, y[cs], a[cs][rs]);
+                    }
+                } else if constexpr (K == 14) {
+                    const double e15 = quad_bcast<1>(a[7][7]);               // M[14][15]: row parity 0, column parity 1
+                    if (writer) dout[31] = e15;
+                }
+            });
+        }
+        __syncthreads();
+    }
+}
+
 // Golub-Kahan implicit-shift QR on one 16x16 bidiagonal per lane (Golub & Reinsch 1970, the
 // diagonalisation half of their SVD procedure, singular values only).  w = diagonal, e =
 // superdiagonal (e[0] unused), both parked lane-major in LDS.  sv out: f64 [nmat][16], unsorted, >= 0.

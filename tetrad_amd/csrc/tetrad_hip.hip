@@ -115,6 +115,7 @@ struct tq_ctx {
     hipStream_t sX = nullptr;       // the second stream of the singular-value stage
     hipEvent_t evFork = nullptr, evJoin = nullptr;
     int svd_method = 1;             // 0 = one-sided Jacobi (tq_svd_kernel), 1 = Householder + bidiagonal QR
+    int bidiag_layout = 1;          // 1 = matrix dealt 2 x 2 over the quad (tq_bidiag2_kernel), 0 = four column groups
     int bdsqr_maxit = 60;           // QR sweeps per singular value before a matrix is declared not converged
     uint64_t *d_bdsqr_stats = nullptr;   // diagnostics (option "bdsqr_stats"): {matrices, rotation steps of all lanes,
                                          // lane-slots issued (64 x wave iterations), sweeps} summed over the launches
@@ -637,7 +638,7 @@ int launch_hqr(tq_ctx *ctx, const uint32_t *cm, const uint32_t *dq, int64_t n, c
     double *sv = ctx->d_sv + (size_t)lane * (size_t)ctx->svd_quartets * 48;
     uint32_t *nsnps = ctx->d_nsnps + (size_t)lane * (size_t)ctx->svd_quartets;
     int64_t grid;
-    auto k1 = tq_bidiag_kernel<DEBUG>;
+    auto k1 = ctx->bidiag_layout ? tq_bidiag2_kernel<DEBUG> : tq_bidiag_kernel<DEBUG>;
     // one pass per block unless told otherwise: the work per pass varies (QR iterations), and the
     // hardware dispatcher balances it better than a static grid-stride loop (3.8 ms vs 5.1 ms per 1e6)
     const int svd_wpc = ctx->svd_wpc > 0 ? ctx->svd_wpc : (1 << 20);
@@ -1437,6 +1438,11 @@ int tq_set_option(tq_ctx *ctx, const char *name, int64_t value)
     }
     if (!strcmp(name, "scan_pair")) {
         ctx->scan_pair = value != 0;
+        return TQ_OK;
+    }
+    if (!strcmp(name, "bidiag_layout")) {
+        if (value < -1 || value > 1) return fail(ctx, TQ_ERR_INVALID_ARG, "bidiag_layout must be -1 (default), 0 or 1");
+        ctx->bidiag_layout = value < 0 ? 1 : (int)value;
         return TQ_OK;
     }
     if (!strcmp(name, "park_t")) {

@@ -81,3 +81,69 @@ for sub in (True, False):
           f"{until6.mean():.1f} ({until6.mean() / tot.mean():.2f} of the total); they are the first six to deflate in "
           f"{inorder / len(mats):.2%} of the matrices; deflations needed: mean {pos.mean():.2f}, max {pos.max()}, "
           f"histogram {np.bincount(pos)[6:].tolist()}")
+
+
+# ---- wave-level cost: 64 lanes in lockstep, every sweep costs the longest block among the lanes that sweep ----
+def sweep_trace(d, e, need=None):
+    """Block length of every sweep of one matrix; with `need` = m the iteration stops as soon as the m smallest singular
+    values are known: at least m have deflated and the still undeflated leading block has no singular value below the
+    m-th smallest deflated one (Sturm count on the block's B^T B; charged as 3 rotation steps)."""
+    w = d.astype(float).copy()
+    ee = np.zeros(16); ee[1:] = e
+    anorm = np.max(np.abs(w) + np.abs(ee))
+    tiny = anorm * 0.5 * EPS
+    k = 15; lens = []; done = []
+    while True:
+        while True:
+            l = k
+            while l > 0 and abs(ee[l]) > tiny and abs(w[l - 1]) > tiny:
+                l -= 1
+            if l != k:
+                break
+            done.append(abs(w[k])); k -= 1
+            if k < 0: return lens
+            if need is not None and len(done) >= need:
+                t = np.sort(done)[need - 1]
+                # Sturm count: number of singular values of the leading (k+1) x (k+1) block below t
+                cnt = 0; qv = w[0] ** 2 - t * t
+                cnt += qv < 0
+                for i in range(1, k + 1):
+                    qv = w[i] ** 2 + ee[i] ** 2 - t * t - (ee[i] ** 2) * (w[i - 1] ** 2) / (qv if qv != 0 else 1e-300)
+                    cnt += qv < 0
+                lens.append(3)
+                if cnt == 0: return lens
+        nm = k - 1
+        x = w[l]; y = w[nm]; g = ee[nm]; h = ee[k]; z = w[k]
+        f = ((y - z) * (y + z) + (g - h) * (g + h)) / (2.0 * h * y)
+        g = np.hypot(f, 1.0)
+        f = ((x - z) * (x + z) + h * (y / (f + np.copysign(g, f)) - h)) / x
+        cc = ss = 1.0
+        for jj in range(l, nm + 1):
+            i = jj + 1
+            g = ee[i]; y = w[i]
+            h = ss * g; g = cc * g
+            zz = np.hypot(f, h); ee[jj] = zz
+            cc = f / zz if zz else 0.0; ss = h / zz if zz else 0.0
+            f = x * cc + g * ss; g = g * cc - x * ss; h = y * ss; y *= cc
+            zz = np.hypot(f, h); w[jj] = zz
+            if zz: cc = f / zz; ss = h / zz
+            f = cc * g + ss * y; x = cc * y - ss * g
+        ee[l] = 0.0; ee[k] = f; w[k] = x
+        lens.append(nm - l + 1)
+
+
+def wave_cost(traces):
+    n = max(len(t) for t in traces)
+    return sum(max((t[i] if i < len(t) else 0) for t in traces) for i in range(n))
+
+
+_, rstat, rscor, dbg = orc.new_infer_resolved_quartets(tmparr, tmpmap, q[:256], True, debug=True)
+mats = dbg["cmats"].reshape(-1, 16, 16).astype(float)
+d, e = dm.bidiagonalize(mats)
+full = [sweep_trace(d[i], e[i]) for i in range(len(mats))]
+part = [sweep_trace(d[i], e[i], need=6) for i in range(len(mats))]
+for name, tr in (("full spectrum", full), ("six smallest", part)):
+    lane = np.mean([sum(t) for t in tr])
+    waves = [wave_cost(tr[i:i + 64]) for i in range(0, len(tr), 64)]
+    print(f"{name}: {lane:.1f} steps per matrix, wave cost {np.mean(waves):.1f} lane-slots per matrix-slot "
+          f"(sweeps per wave {np.mean([max(len(t) for t in tr[i:i+64]) for i in range(0, len(tr), 64)]):.1f})")

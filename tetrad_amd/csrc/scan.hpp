@@ -2,6 +2,15 @@
 // Part of the single translation unit tetrad_hip.hip (included inside its anonymous namespace).
 #pragma once
 
+// The hand-written instruction sequences below (walk_set_bits, the slot macros, the subsample carry, the park stores)
+// are gfx9 / CDNA encodings for 64-lane wavefronts: vcc and exec as 64-bit masks, v_add_co_u32 with an SGPR-pair carry-out,
+// LDS instructions without M0 set-up, ds_write_addtid_b32.  They are entered with ALL 64 lanes active (a working wave of
+// a full workgroup; count_from_candidates reads carries as lane masks).  -DTQ_NO_ASM builds the plain C++ form of every one
+// of them: the reference form for A/B runs (tools/ab) and the starting point of a port -- same results, bit for bit.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__) && !defined(TQ_NO_ASM)
+#error "scan.hpp: the inline assembly is written for gfx950 (CDNA4, wave64); build with --offload-arch=gfx950 or -DTQ_NO_ASM"
+#endif
+
 // ------------------------------------------------------------------------------------
 // kernel 1: site scan -> 256-bin pattern histogram
 // ------------------------------------------------------------------------------------
@@ -43,9 +52,24 @@ template <bool SUB>
 __device__ __forceinline__ uint32_t count_from_candidates(uint32_t U, uint32_t B, int lane, uint32_t &tile_carry)
 {
     if (!SUB) return U;
-    (void)lane;
+    (void)lane;                                              // (precondition of the asm form: all 64 lanes active)
     const uint32_t P = ~B;
     const uint32_t X = U | P;
+#ifdef TQ_NO_ASM
+    const uint64_t s64 = (uint64_t)X + (uint64_t)U;
+    const uint32_t sum = (uint32_t)s64;
+    const uint64_t Gm = __ballot((uint32_t)(s64 >> 32) != 0u);      // lanes whose in-lane add carries out: "generate"
+    const uint32_t cin0 = sum ^ X ^ U;
+    const uint32_t seen_local = P & cin0;
+    const uint64_t Pm = __ballot(B == 0);
+    const uint64_t Xm = Gm | Pm;
+    const uint32_t cin_tile = __builtin_amdgcn_readfirstlane(tile_carry) != 0u ? 1u : 0u;
+    const unsigned __int128 t128 = (unsigned __int128)Xm + (unsigned __int128)Gm + cin_tile;
+    const uint64_t cinm = (uint64_t)t128 ^ Xm ^ Gm;
+    tile_carry = (uint32_t)(t128 >> 64);
+    const uint32_t notfirst = B | (0u - B);
+    const uint32_t inherit = ((cinm >> lane) & 1ull) ? notfirst : 0xFFFFFFFFu;
+#else
     // in-lane: X + U; its carry-out IS t(31), so the per-lane "generate" flags of the lane-to-lane chain come out of
     // the add itself as a 64-bit lane mask (the sdst of v_add_co_u32) -- no bit fiddling, no compare, no ballot
     uint32_t sum;
@@ -75,6 +99,7 @@ __device__ __forceinline__ uint32_t count_from_candidates(uint32_t U, uint32_t B
     // cinm is used as what it is -- a lane mask -- by one v_cndmask (the compiler would shift it by the lane id)
     uint32_t inherit;
     asm("v_cndmask_b32_e64 %0, -1, %1, %2" : "=v"(inherit) : "v"(notfirst), "s"(cinm));      // cin ? notfirst : ~0
+#endif
     return U & ~seen_local & inherit;                        // = U & ~(seen_local | (cin ? ~notfirst : 0))
 }
 
@@ -142,6 +167,12 @@ __device__ __forceinline__ uint32_t lds_offset(const void *p) { return (uint32_t
 #else
 #define TQ_WALK_PRIO_ON
 #define TQ_WALK_PRIO_OFF
+#endif
+#ifdef TQ_NO_ASM
+#define TQ_PARK_ADDTID 0
+constexpr bool USE_ASM = false;
+#else
+constexpr bool USE_ASM = true;
 #endif
 #ifndef TQ_PARK_ADDTID
 #define TQ_PARK_ADDTID 1
@@ -256,7 +287,7 @@ __device__ __forceinline__ void hist_patterns(const uint32_t (&pat)[8], uint32_t
         after_build();
     } else if (METHOD == 0) {
         after_build();
-        if (NREP == 1) {
+        if (NREP == 1 && USE_ASM) {
             // one EXEC-masked ds_add per site slot, most significant bit first: v_add_co c, vcc, c, c shifts the count
             // mask and hands the slot's bit over AS the lane mask (its carry-out), so a slot is 3 vector instructions
             // (that add, the byte extract, the bin address) where the compiler's version tests the bit with an AND and
@@ -318,15 +349,18 @@ __device__ __forceinline__ void hist_patterns(const uint32_t (&pat)[8], uint32_t
             for (int j = 0; j < 8; ++j) pw[PARK_T ? j * WAVE : j] = pat[j];     // PARK_T: `park` = row 0 of the wave + lane * 4
         }
         after_build();
-        if (NREP == 1) {
+        if (NREP == 1 && USE_ASM) {
             walk_set_bits<METHOD != 4, PARK_T>(C, lds_offset(park), lds_offset(hrep));
         } else {
-            // set-bit walk (replicated histograms: the one-wave-per-quartet kernel's A/B option)
+            // set-bit walk in plain C++ (replicated histograms: the one-wave-per-quartet kernel's A/B option; every form
+            // under -DTQ_NO_ASM).  Transposed park: byte i of the lane sits in row i >> 2 (256 bytes per row) at lane * 4 + (i & 3)
             uint32_t c = C;
             while (c) {
-                uint32_t *p0 = hrep + (uint32_t)park[__builtin_ctz(c)] * NREP;
+                const int i = __builtin_ctz(c);
+                const uint32_t b = PARK_T ? park[(i >> 2) * (WAVE * 4) + (i & 3)] : park[i];
                 c &= c - 1;
-                __hip_atomic_fetch_add(p0, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (METHOD != 4)
+                    __hip_atomic_fetch_add(hrep + b * NREP, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
         }
     }
@@ -485,12 +519,28 @@ __device__ __forceinline__ void pin4(uint4 &v)
     asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w));
 }
 
+// 0x0f0f0f0f in an SGPR (as a literal it cannot be encoded in the three-operand v_and_or_b32)
+__device__ __forceinline__ uint32_t sgpr_const_0f()
+{
+#ifdef TQ_NO_ASM
+    return 0x0f0f0f0fu;
+#else
+    uint32_t m;
+    asm("s_mov_b32 %0, 0x0f0f0f0f" : "=s"(m));
+    return m;
+#endif
+}
+
 // (a & m) | c in one instruction; m must sit in an SGPR (the compiler emits v_and + v_or otherwise)
 __device__ __forceinline__ uint32_t and_or(uint32_t a, uint32_t m, uint32_t c)
 {
+#ifdef TQ_NO_ASM
+    return (a & m) | c;
+#else
     uint32_t r;
     asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(m), "v"(c));
     return r;
+#endif
 }
 
 // 12-byte load (one compact plane record {miss, p0, p1}); .w of the result is 0
@@ -747,7 +797,7 @@ tq_scan_wg_kernel(DevData d, const uint32_t *__restrict__ quartets, const uint32
                 // (the mask lives in an SGPR so that (s & m) | ab is one v_and_or_b32; as a literal it
                 // cannot be encoded in a three-operand instruction and costs a second one)
                 uint32_t m;
-                asm("s_mov_b32 %0, 0x0f0f0f0f" : "=s"(m));
+                m = sgpr_const_0f();
                 const uint32_t s0 = (own.c.x << 2) + own.d.x, s1 = (own.c.y << 2) + own.d.y, s2 = (own.c.z << 2) + own.d.z,
                                s3 = (own.c.w << 2) + own.d.w;
                 uint32_t pat[8];
@@ -996,7 +1046,7 @@ tq_scan_wg2_kernel(DevData d, const uint32_t *__restrict__ quartets, const uint3
                     }
                     const uint32_t C = count_mask_shared<SUB>(r1, Bw, pcc, pdd, lane, carry);
                     uint32_t m;
-                    asm("s_mov_b32 %0, 0x0f0f0f0f" : "=s"(m));
+                    m = sgpr_const_0f();
                     const uint32_t s0 = (cc.x << 2) + dd.x, s1 = (cc.y << 2) + dd.y, s2 = (cc.z << 2) + dd.z,
                                    s3 = (cc.w << 2) + dd.w;
                     uint32_t pat[8];

@@ -175,7 +175,7 @@ tq_scan_pb_kernel(DevData d, const uint32_t *__restrict__ quartets, const uint32
                     }
                     uint32_t c = count_mask_shared<SUB>(I.r1, SUB ? I.Bw : 0u, R.pc, R.pd, lane, tile_carry);
                     uint32_t m;
-                    asm("s_mov_b32 %0, 0x0f0f0f0f" : "=s"(m));
+                    m = sgpr_const_0f();
                     const uint32_t s0 = (R.c.x << 2) + R.d.x, s1 = (R.c.y << 2) + R.d.y, s2 = (R.c.z << 2) + R.d.z,
                                    s3 = (R.c.w << 2) + R.d.w;
                     uint32_t pat[8];
@@ -194,6 +194,22 @@ tq_scan_pb_kernel(DevData d, const uint32_t *__restrict__ quartets, const uint32
                     // counter address {base.3, base.2, pattern byte, base.0}; then the four atomics, each under its mask.
                     // Vector work and atomics are kept apart so that no atomic waits for a mask that is still on its way
                     // from the vector to the scalar unit (with two waves per SIMD nobody hides that latency).
+#ifdef TQ_NO_ASM
+                    // plain C++ form of the 32 slots (reference form, scan.hpp): counter of bin b for this lane =
+                    // dword b * 64 + pair * 32 + (lane mod 32)
+                    {
+                        uint32_t *col = S.hist + (uint32_t)(w >> 1) * 32u + (uint32_t)(lane & 31);
+#pragma unroll
+                        for (int j = 7; j >= 0; --j) {
+#pragma unroll
+                            for (int k = 3; k >= 0; --k) {
+                                if (c & (1u << (4 * j + k)))
+                                    __hip_atomic_fetch_add(col + ((pat[j] >> (8 * k)) & 0xFFu) * 64u, inc, __ATOMIC_RELAXED,
+                                                           __HIP_MEMORY_SCOPE_WORKGROUP);
+                            }
+                        }
+                    }
+#else
                     uint32_t sel0, sel1, sel2, sel3;                 // D.byte1 <- S0.byte K (selector 4 + K), the rest <- S1
                     uint64_t save;
                     asm volatile("s_mov_b32 %0, 0x03020400\n\ts_mov_b32 %1, 0x03020500\n\ts_mov_b32 %2, 0x03020600\n\t"
@@ -229,6 +245,7 @@ tq_scan_pb_kernel(DevData d, const uint32_t *__restrict__ quartets, const uint32
                     TQ_PB_SLOT4(7) TQ_PB_SLOT4(6) TQ_PB_SLOT4(5) TQ_PB_SLOT4(4) TQ_PB_SLOT4(3) TQ_PB_SLOT4(2) TQ_PB_SLOT4(1)
                     TQ_PB_SLOT4(0)
 #undef TQ_PB_SLOT4
+#endif
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 // the image words of step t + 2 are "defined" here for the compiler: the copies that assemble the 16-byte

@@ -1,9 +1,9 @@
-# The command list behind profiles/r03_final/ (run on the GPU box through gpurun; every rocprofv3 pass under a timeout:
+# The command list behind profiles/rNN_final/ (round 4: profiles/r04_final/) (run on the GPU box through gpurun; every rocprofv3 pass under a timeout:
 # a profiler that aborts on an over-subscribed counter set hangs afterwards).
 set -e
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-O=gpurun_out/r3prof
+O=${1:-gpurun_out/r4prof}
 rm -rf $O; mkdir -p $O
 P="timeout -k 5 240 rocprofv3"
 $P --kernel-trace --stats -d $O/stats --output-format csv -- python3 bench.py --no-cpu --steps 8 --warmup 2 > $O/bench_under_rocprof.json 2> $O/stats.err

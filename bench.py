@@ -321,6 +321,8 @@ def parse_args(argv=None):
     ap.add_argument("--quartets", type=int, default=0, help="quartets in the batch (0 = config default)")
     ap.add_argument("--full", action="store_true", help="subsample_snps=False")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--no-other-mode", action="store_true",
+                    help="skip the 3 steps in the other subsample mode (full_mode_value): profiler passes average per kernel name")
     ap.add_argument("--cpu-procs", type=int, default=0,
                     help="processes of the cpu_baseline leg (0 = one per physical core this process may use)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -716,15 +718,16 @@ def main(argv=None):
         # the other mode of the same workload through the timed path (3 steps after one warm-up): the reference's
         # DEFAULT is subsample_snps=False (cli_init.py:61 is store_true), north_star's primary is True -- the driver's
         # record carries both
-        out_o = (pinned_empty((Q, 2), np.uint32), pinned_empty((Q, 3), np.float64), pinned_empty(Q, np.uint8))
-        eng.resolve_to_host(d_q.data_ptr(), Q, not sub, out=out_o)
-        t1 = time.perf_counter()
-        for _ in range(3):
+        if not args.no_other_mode:             # (profiling passes skip it: per-kernel averages must be of ONE mode)
+            out_o = (pinned_empty((Q, 2), np.uint32), pinned_empty((Q, 3), np.float64), pinned_empty(Q, np.uint8))
             eng.resolve_to_host(d_q.data_ptr(), Q, not sub, out=out_o)
-        other = 3 * Q / (time.perf_counter() - t1)
-        extra["subsample_mode_value" if not sub else "full_mode_value"] = other
-        extra["other_mode_flags"] = {"zero_data": int((out_o[2] & 1).sum()), "degenerate": int(((out_o[2] & 2) > 0).sum()),
-                                     "nsnps_mean": float(out_o[0][:, 1].mean())}
+            t1 = time.perf_counter()
+            for _ in range(3):
+                eng.resolve_to_host(d_q.data_ptr(), Q, not sub, out=out_o)
+            other = 3 * Q / (time.perf_counter() - t1)
+            extra["subsample_mode_value" if not sub else "full_mode_value"] = other
+            extra["other_mode_flags"] = {"zero_data": int((out_o[2] & 1).sum()), "degenerate": int(((out_o[2] & 2) > 0).sum()),
+                                         "nsnps_mean": float(out_o[0][:, 1].mean())}
     else:
         r = run_sharded(wl, args.steps, args.warmup)
         elapsed, kms, launches, q_rank = r["elapsed"], r["kms"], r["launches"], r["n_local"]

@@ -11,10 +11,10 @@ TQ_LIB_PATH=tools/ab/libtetrad_nonib.so bash tools/scan_pmc.sh $O "nonib:" >> $O
 for L in base nonib; do
   if [ $L = nonib ]; then export TQ_LIB_PATH=tools/ab/libtetrad_nonib.so; fi
   rm -rf $O/$L.m
-  timeout -k 5 150 rocprofv3 --kernel-trace --pmc TA_TA_BUSY_sum TA_FLAT_READ_WAVEFRONTS_sum -d $O/$L.m --output-format csv -- python3 bench.py --phases 1 --no-cpu --steps 3 --warmup 1 > /dev/null 2> $O/$L.m.err
+  timeout -k 5 150 rocprofv3 --kernel-trace --pmc TA_TA_BUSY_sum TA_FLAT_READ_WAVEFRONTS_sum -d $O/$L.m --output-format csv -- python3 bench.py --no-other-mode --phases 1 --no-cpu --steps 3 --warmup 1 > /dev/null 2> $O/$L.m.err
   python3 tools/pmc_kernel.py tq_scan_ $O/$L.m >> $O/$L.txt
   rm -rf $O/$L.m
-  timeout -k 5 150 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_BUSY_CU_CYCLES -d $O/$L.m --output-format csv -- python3 bench.py --phases 1 --no-cpu --steps 3 --warmup 1 > /dev/null 2>> $O/$L.m.err
+  timeout -k 5 150 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_BUSY_CU_CYCLES -d $O/$L.m --output-format csv -- python3 bench.py --no-other-mode --phases 1 --no-cpu --steps 3 --warmup 1 > /dev/null 2>> $O/$L.m.err
   python3 tools/pmc_kernel.py tq_scan_ $O/$L.m >> $O/$L.txt
   rm -rf $O/$L.m
 done

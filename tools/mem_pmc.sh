@@ -14,7 +14,7 @@ for v in "$@"; do
              "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum" "TCP_PENDING_STALL_CYCLES_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum" \
              "TD_TD_BUSY_sum TD_TC_STALL_sum" "GRBM_GUI_ACTIVE SQ_BUSY_CU_CYCLES SQ_WAVES SQ_INSTS_VMEM"; do
     rm -rf $O/$L.m
-    timeout -k 5 150 rocprofv3 --kernel-trace --pmc $set -d $O/$L.m --output-format csv -- python3 bench.py --phases 1 --no-cpu --steps 3 --warmup 1 $A > /dev/null 2> $O/$L.m.err || echo "pass failed: $set" >> $O/$L.mem.txt
+    timeout -k 5 150 rocprofv3 --kernel-trace --pmc $set -d $O/$L.m --output-format csv -- python3 bench.py --no-other-mode --phases 1 --no-cpu --steps 3 --warmup 1 $A > /dev/null 2> $O/$L.m.err || echo "pass failed: $set" >> $O/$L.mem.txt
     python3 tools/pmc_kernel.py tq_scan_ $O/$L.m >> $O/$L.mem.txt
     rm -rf $O/$L.m
   done

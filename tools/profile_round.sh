@@ -6,14 +6,14 @@ export TMPDIR=/tmp
 O=${1:-gpurun_out/r4prof}
 rm -rf $O; mkdir -p $O
 P="timeout -k 5 240 rocprofv3"
-$P --kernel-trace --stats -d $O/stats --output-format csv -- python3 bench.py --no-cpu --steps 8 --warmup 2 > $O/bench_under_rocprof.json 2> $O/stats.err
+$P --kernel-trace --stats -d $O/stats --output-format csv -- python3 bench.py --no-other-mode --no-cpu --steps 8 --warmup 2 > $O/bench_under_rocprof.json 2> $O/stats.err
 echo stats done
-$P --kernel-trace --pmc FETCH_SIZE -d $O/pmc_f --output-format csv -- python3 bench.py --no-cpu --steps 4 --warmup 1 > /dev/null 2> $O/pmc_f.err
-$P --kernel-trace --pmc WRITE_SIZE -d $O/pmc_w --output-format csv -- python3 bench.py --no-cpu --steps 4 --warmup 1 > /dev/null 2> $O/pmc_w.err
+$P --kernel-trace --pmc FETCH_SIZE -d $O/pmc_f --output-format csv -- python3 bench.py --no-other-mode --no-cpu --steps 4 --warmup 1 > /dev/null 2> $O/pmc_f.err
+$P --kernel-trace --pmc WRITE_SIZE -d $O/pmc_w --output-format csv -- python3 bench.py --no-other-mode --no-cpu --steps 4 --warmup 1 > /dev/null 2> $O/pmc_w.err
 echo traffic done
-$P --kernel-trace --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_INSTS_SALU SQ_WAIT_INST_LDS SQ_WAIT_ANY SQ_INSTS_VMEM -d $O/sq1 --output-format csv -- python3 bench.py --no-cpu --steps 3 --warmup 1 > /dev/null 2> $O/sq1.err
-$P --kernel-trace --pmc SQ_INSTS_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS -d $O/sq2 --output-format csv -- python3 bench.py --no-cpu --steps 3 --warmup 1 > /dev/null 2> $O/sq2.err
-$P --kernel-trace --pmc TA_TA_BUSY_sum TA_FLAT_READ_WAVEFRONTS_sum -d $O/sq3 --output-format csv -- python3 bench.py --no-cpu --steps 3 --warmup 1 > /dev/null 2> $O/sq3.err || true
+$P --kernel-trace --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_INSTS_SALU SQ_WAIT_INST_LDS SQ_WAIT_ANY SQ_INSTS_VMEM -d $O/sq1 --output-format csv -- python3 bench.py --no-other-mode --no-cpu --steps 3 --warmup 1 > /dev/null 2> $O/sq1.err
+$P --kernel-trace --pmc SQ_INSTS_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS -d $O/sq2 --output-format csv -- python3 bench.py --no-other-mode --no-cpu --steps 3 --warmup 1 > /dev/null 2> $O/sq2.err
+$P --kernel-trace --pmc TA_TA_BUSY_sum TA_FLAT_READ_WAVEFRONTS_sum -d $O/sq3 --output-format csv -- python3 bench.py --no-other-mode --no-cpu --steps 3 --warmup 1 > /dev/null 2> $O/sq3.err || true
 echo pmc done
 python3 tools/pmc_traffic.py $O/pmc_f $O/pmc_w --out $O/traffic_c3_sub.json --commit $(cat .build_commit) --copy-to $O/csv
 python3 tools/pmc_busy.py $O/sq1 $O/sq2 $O/sq3 --out $O/pmc_busy.json --source "rocprofv3 --pmc passes of python3 bench.py --no-cpu (c3 sub)" --commit $(cat .build_commit)

@@ -328,6 +328,10 @@ def parse_args(argv=None):
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo = rehearsal of the N>1 control flow on a box with fewer GPUs than ranks")
     ap.add_argument("--pieces", type=int, default=0, help="N > 1: result pieces per batch (0 = automatic)")
+    ap.add_argument("--no-gather-ab", action="store_true", help="N > 1: skip the short leg with the other --gather mode")
+    ap.add_argument("--gather", default="collective", choices=["collective", "host"],
+                    help="N > 1: 'collective' = one all-gather per piece, rank 0 copies the rows D2H (default); 'host' = every "
+                         "rank copies its own rows D2H into rank 0's shared page-locked arrays, no collective on the data path")
     ap.add_argument("--sharded", action="store_true",
                     help="take the N > 1 code path (process group, all-gather per piece, regrouping, verification) "
                          "even with one rank: a one-GPU rehearsal of the RCCL path")
@@ -568,13 +572,13 @@ def main(argv=None):
         torch.cuda.synchronize()
         return n * steps / (time.perf_counter() - t0), out, d_q
 
-    def run_sharded(wl, steps, warmup, timing=True):
+    def run_sharded(wl, steps, warmup, timing=True, gather=None, with_one_gpu=True):
         """The N-rank path over workload `wl`: returns a dict with the max-over-ranks elapsed time of `steps`
         steps, the gathered rows (rank 0), the verification of the gather and the in-run one-GPU figure."""
         from tetrad_amd.distributor import ShardedResolver
         Q = wl["Q"]
         res = ShardedResolver(Q, engine=eng, device=dev_index, dst=0, pieces=args.pieces or None,
-                              collective_always=True)
+                              collective_always=True, gather=gather or args.gather)
         res.set_ranks(wl["ranks_all"])
         torch.cuda.synchronize()
         last = [None]
@@ -600,12 +604,15 @@ def main(argv=None):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
         rstat, rscor, flags = last[0]
+        if res.gather == "host" and rstat is not None:          # views of the shared segment, which res.close() unmaps
+            rstat, rscor, flags = rstat.copy(), rscor.copy(), flags.copy()
+        last[0] = None
         # the gathered rows on rank 0 against what every rank computed itself: a checksum over each rank's
         # own rows and 64 sampled rows per rank, compared bit for bit
         P = res.plan
-        own = res.device_rows()
-        idx = torch.from_numpy(P.local_index(rank)).to(own[0].device)
-        mine = [x.index_select(0, idx) for x in own] if len(idx) else None
+        own = res.local_rows()                     # what this rank's kernels produced (its slabs), either gather mode
+        idx = P.local_index(rank)
+        mine = list(own) if len(idx) else None
         pick = np.random.default_rng(rank).integers(0, max(1, len(idx)), size=min(64, len(idx)))
         rec = dict(rank=rank, n=int(len(idx)),
                    nsnps_sum=int(mine[0][:, 1].to(torch.int64).sum().item()) if mine else 0,
@@ -628,10 +635,11 @@ def main(argv=None):
         # the like-for-like one-GPU figure, MEASURED IN THIS RUN: rank 0 alone resolves the same quartets one GPU
         # would own in the single-GPU form of this workload (strong: the whole batch; weak: one rank's 1/N share)
         # through tq_resolve_to_host while the other ranks wait at the barrier
+        res.close()
         del res, own, mine, idx
         torch.cuda.empty_cache()
         barrier()
-        if rank == 0:
+        if rank == 0 and with_one_gpu:
             ranks1 = wl["ranks_all"] if not wl["weak"] else wl["ranks_all"][:Q // world]
             v1, out1, _ = one_gpu_pass(ranks1, min(3, steps))
             out["one_gpu_same_run_value"] = v1
@@ -742,6 +750,19 @@ def main(argv=None):
             extra["speedup_note"] = ("value / one_gpu_same_run_value: rank 0 alone, same run, "
                                      + ("one rank's share of the batch (weak scaling: ideal = n_gpus)" if weak
                                         else "the whole batch (strong scaling: ideal = n_gpus)"))
+        # the same workload with the OTHER way of getting the rows to rank 0 (a few steps, same run): one of the two A/Bs
+        # DESIGN.md section 6 wants measured on a multi-GPU node before either is trusted as the default
+        if not args.no_gather_ab:
+            other = "host" if args.gather == "collective" else "collective"
+            ro = run_sharded(wl, min(args.steps, 3), 1, timing=False, gather=other, with_one_gpu=False)
+            if rank == 0:
+                vo = Q * min(args.steps, 3) / ro["elapsed"]
+                extra["other_gather_leg"] = dict(
+                    gather=other, value=vo, unit="quartets/s", steps=min(args.steps, 3),
+                    ms_per_step=ro["elapsed"] / min(args.steps, 3) * 1e3, gather_verified=ro["gather_verified"],
+                    rows_equal_main_leg=bool(np.array_equal(ro["rows"][0], rstat) and np.array_equal(ro["rows"][1], rscor)),
+                    what=("every rank copies its own rows D2H into rank 0's shared page-locked arrays, no collective on the "
+                          "data path" if other == "host" else "one all-gather per result piece, rank 0 copies the rows D2H"))
         # secondary leg of the default N > 1 run: BASELINE.json configs[3] (c4, ONE 5e6-quartet batch cut over the
         # ranks: strong scaling) with its own in-run one-GPU figure
         if cfg == "c3" and not args.config and not args.no_c4_leg and not args.quartets:
@@ -788,7 +809,10 @@ def main(argv=None):
             "vs_baseline": None,
             "dtype": "u8 scan / u32 counts / f64 SVD", "data": "synthetic",
             "config": {"workload": workload, "quartets": Q, "taxa": T, "snps": S, "subsample_snps": sub,
-                       "parallelism": (f"quartet-sharded x{world}, one all-gather per result piece, rows to rank 0's host"
+                       "parallelism": ((f"quartet-sharded x{world}, one all-gather per result piece, rows to rank 0's host"
+                                        if args.gather == "collective" else
+                                        f"quartet-sharded x{world}, every rank copies its rows D2H into rank 0's shared "
+                                        f"page-locked arrays (--gather host), no collective on the data path")
                                        if multi else "one GPU, result D2H overlapped inside tq_resolve_to_host"),
                        "launcher": ("bench.py started the ranks itself" if os.environ.get("TQ_BENCH_SELF_LAUNCHED")
                                     else ("torch.distributed.run / external" if multi else "none (one process)")),

@@ -120,6 +120,14 @@ def compute(tmparr, tmpmap, q, sub):
 qr = g["quartets"][:101]                       # odd count: exercises the padded slab
 _, rstat, rscor, flags = D.resolve_sharded(g["tmparr"], g["tmpmap"], qr, True, compute=compute)
 np.savez(out + f".{rank}.npz", rstat=rstat, rscor=rscor, flags=flags)
+# no collective: every rank writes its rows into a shared host segment (gather="host"), rows to every rank / to rank 0
+_, rs_h, rc_h, fl_h = D.resolve_sharded(g["tmparr"], g["tmpmap"], qr, True, compute=compute, pieces=2, gather="host")
+np.savez(out + f".host.{rank}.npz", rstat=rs_h, rscor=rc_h, flags=fl_h)
+_, rs_h0, rc_h0, fl_h0 = D.resolve_sharded(g["tmparr"], g["tmpmap"], qr, False, compute=compute, gather="host", dst=0)
+if rank == 0:
+    np.savez(out + ".host0.npz", rstat=rs_h0, rscor=rc_h0, flags=fl_h0)
+else:
+    assert rs_h0 is None and rc_h0 is None and fl_h0 is None
 # several pieces (one all-gather each), rows to rank 0 only
 _, rstat3, rscor3, flags3 = D.resolve_sharded(g["tmparr"], g["tmpmap"], qr, True, compute=compute, pieces=3, dst=0)
 if rank == 0:
@@ -162,6 +170,15 @@ def test_two_rank_gloo_gather_equals_single_rank(tmp_path, oracle):
     z = np.load(out + ".p3.npz")
     np.testing.assert_array_equal(z["rstat"], rstat)
     np.testing.assert_array_equal(z["rscor"], rscor)
+    # gather="host": the shared-segment path gives the same rows, on every rank and on rank 0 alone (other mode)
+    for r in range(2):
+        z = np.load(out + f".host.{r}.npz")
+        np.testing.assert_array_equal(z["rstat"], rstat)
+        np.testing.assert_array_equal(z["rscor"], rscor)
+    _, rstat_f, rscor_f = oracle.new_infer_resolved_quartets(g["tmparr"], g["tmpmap"], g["quartets"][:101], False)
+    z = np.load(out + ".host0.npz")
+    np.testing.assert_array_equal(z["rstat"], rstat_f)
+    np.testing.assert_array_equal(z["rscor"], rscor_f)
     # rank 0 wrote all chunks in order, 9 columns
     rows = Path(out + ".tsv").read_text().splitlines()
     assert len(rows) == 101

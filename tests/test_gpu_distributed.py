@@ -30,6 +30,9 @@ qr = g["quartets"][:1501]                      # odd count: exercises the padded
 for sub in (True, False):
     _, rstat, rscor, flags = D.resolve_sharded(g["tmparr"], g["tmpmap"], qr, sub, pieces=(3 if sub else None))
     np.savez(out + f".{int(sub)}.{rank}.npz", rstat=rstat, rscor=rscor, flags=flags)
+    # the alternative without a collective: every rank's rows D2H into a shared page-locked segment
+    _, rstat, rscor, flags = D.resolve_sharded(g["tmparr"], g["tmpmap"], qr, sub, pieces=(2 if sub else None), gather="host")
+    np.savez(out + f".host.{int(sub)}.{rank}.npz", rstat=rstat, rscor=rscor, flags=flags)
 db = out + ".db.npz"
 if rank == 0:
     np.savez(db, tmparr=g["tmparr"], tmpmap=g["tmpmap"])
@@ -81,10 +84,11 @@ def test_two_ranks_with_the_engine_equal_one_engine(tmp_path):
     for sub in (True, False):
         rstat, rscor, flags = eng.resolve(q, sub)
         for r in range(2):
-            z = np.load(out + f".{int(sub)}.{r}.npz")
-            np.testing.assert_array_equal(z["rstat"], rstat)
-            np.testing.assert_array_equal(z["rscor"], rscor)
-            np.testing.assert_array_equal(z["flags"], flags)
+            for tag in ("", ".host"):
+                z = np.load(out + f"{tag}.{int(sub)}.{r}.npz")
+                np.testing.assert_array_equal(z["rstat"], rstat)
+                np.testing.assert_array_equal(z["rscor"], rscor)
+                np.testing.assert_array_equal(z["flags"], flags)
     rstat, rscor, _ = eng.resolve(q, True)
     assert Path(out + ".tsv").read_text() == D.format_tsv(q, rscor, rstat)
     eng.close()
@@ -118,6 +122,13 @@ def test_bare_bench_command_runs_two_ranks():
     assert len(lines) == 1
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["scaling"] == "weak"
+    # the same with --gather host (no collective on the data path)
+    r = subprocess.run([sys.executable, str(REPO / "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "2",
+                        "--warmup", "1", "--quartets", "40000", "--gather", "host", "--no-c4-leg"], capture_output=True,
+                       text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.strip()][0])
+    assert d["n_gpus"] == 2 and d["gather_verified"] and d["one_gpu_rows_equal_gathered_rows"]
     assert d["config"]["quartets"] == 80000                      # weak: every rank its own 40 000
     assert d["gather_verified"] is True
     assert d["one_gpu_rows_equal_gathered_rows"] is True

@@ -511,6 +511,45 @@ def test_hqr_and_jacobi_agree_on_stress_data(oracle, T, S, seed, p, missing, sub
             assert np.linalg.matrix_rank(d0["cmats"][qi, t].astype(np.float64)) == d1["ranks"][qi, t]
 
 
+@pytest.mark.parametrize("T,S,seed,p,missing", [(11, 700, 21, 0.01, 0.35), (12, 3000, 22, 0.05, 0.1), (10, 300, 23, 0.3, 0.0)])
+def test_bidiag_layouts_agree(T, S, seed, p, missing):
+    """The two lane layouts of the Householder bidiagonalisation (2 x 2 over the quad, the default, and four column groups)
+    apply the same reflectors in a different summation order: identical ranks, nsnps and topologies on unflagged rows,
+    singular values and scores to rounding, on sparse (rank-deficient), dense and saturated inputs; small batches (one block per
+    flattening) and large ones."""
+    from tetrad_amd import synth
+    from tetrad_amd.engine import QuartetEngine
+    tmparr, tmpmap = synth.simulate_tmparr(T, S, seed=seed, p=p, missing=missing)
+    q = synth.all_quartets(T)
+    q = np.concatenate([q] * (1 + 40000 // len(q)))[:40000] if S == 3000 else q      # one case above the tsplit threshold
+    with QuartetEngine(0) as eng:
+        eng.set_data(tmparr, tmpmap)
+        for sub in (True, False):
+            res = {}
+            for layout in (1, 0):
+                eng.set_option("bidiag_layout", layout)
+                res[layout] = eng.resolve(q[:3000], sub, debug=True) if len(q) > 3000 else eng.resolve(q, sub, debug=True)
+                if len(q) > 3000:
+                    res[layout, "big"] = eng.resolve(q, sub)
+            eng.set_option("bidiag_layout", -1)
+            (r1, s1, f1, d1), (r0, s0, f0, d0) = res[1], res[0]
+            np.testing.assert_array_equal(r1[:, 1], r0[:, 1])
+            np.testing.assert_array_equal(d1["ranks"], d0["ranks"])
+            smax = np.maximum(d0["svds"].max(axis=(1, 2)), 1e-300)
+            assert np.abs(d1["svds"] - d0["svds"]).max() <= 1e-11 * smax.max()
+            assert_close(s1, s0, smax[:, None], "scores, 2 x 2 layout vs column layout")
+            ok = ((f1 | f0) & 3) == 0
+            np.testing.assert_array_equal(r1[ok, 0], r0[ok, 0])
+            if len(q) > 3000:
+                (rb1, sb1, fb1), (rb0, sb0, fb0) = res[1, "big"], res[0, "big"]
+                np.testing.assert_array_equal(rb1[:, 1], rb0[:, 1])
+                okb = ((fb1 | fb0) & 3) == 0
+                np.testing.assert_array_equal(rb1[okb, 0], rb0[okb, 0])
+                # chunk invariance across the tsplit threshold: the first 3000 rows of the big batch == the small batch
+                np.testing.assert_array_equal(rb1[:3000], r1)
+                np.testing.assert_array_equal(sb1[:3000], s1)
+
+
 def test_unsorted_and_repeated_taxon_indices(engine, oracle):
     """The reference accepts any four row indices (order matters, repeats allowed); so must the engine."""
     from tetrad_amd import synth

@@ -148,14 +148,27 @@ class ShardedResolver:
              (CPU tests of the partition / gather / regroup logic)
     dst      rank that receives the host arrays (None: every rank)
     nbuf     independent buffer sets: `start(b=k)` / `finish(b=k)` of different sets may be in flight together
+    gather   "collective" (default): one all-gather per piece (RCCL over xGMI / gloo), every rank ends up with all rows on
+             its gather device, the destination copies them D2H over ITS PCIe link.
+             "host": no collective on the data path -- the destination's arrays live in ONE page-locked shared-memory
+             segment that every rank of the node maps and registers with HIP; every rank copies its own rows D2H straight
+             to their global positions over its OWN PCIe link (three copies per piece, no regrouping: a rank's part of a
+             piece is a contiguous row range) and a barrier per batch tells the destination that all parts have landed.
+             Built as the alternative to measure first on a multi-GPU node (on an 8-GPU step the
+             collective path funnels 264 MB through rank 0's link); one node only; `device_rows()` is not available; the
+             returned arrays are views of the segment, valid until the next start() on the same buffer set.
     """
 
     def __init__(self, Q: int, *, engine=None, compute: Optional[Callable] = None, group=None, device=None,
-                 pieces: Optional[int] = None, dst: Optional[int] = None, nbuf: int = 1, collective_always: bool = False):
+                 pieces: Optional[int] = None, dst: Optional[int] = None, nbuf: int = 1, collective_always: bool = False,
+                 gather: str = "collective"):
         import torch
         import torch.distributed as dist
         if (engine is None) == (compute is None):
             raise ValueError("give either `engine` (device path) or `compute` (injected host compute)")
+        if gather not in ("collective", "host"):
+            raise ValueError("gather must be 'collective' or 'host'")
+        self.gather = gather
         self.torch, self.dist, self.group = torch, dist, group
         if dist.is_available() and dist.is_initialized():
             self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
@@ -165,7 +178,7 @@ class ShardedResolver:
         self.engine, self.compute, self.dst = engine, compute, dst
         # a process group of ONE rank normally skips the collective; `collective_always` issues it anyway (a
         # one-GPU rehearsal of the RCCL code path: communicator set-up, uint8 all-gather, stream hand-over)
-        self.collective = self.world > 1 or (collective_always and self.backend is not None)
+        self.collective = (self.world > 1 or (collective_always and self.backend is not None)) and gather == "collective"
         self.plan = ShardPlan(Q, self.world, pieces)
         self.Q = int(Q)
         self.ranges = self.plan.local_ranges(self.rank)
@@ -195,6 +208,68 @@ class ShardedResolver:
         self.side = torch.cuda.Stream(self.dev) if self.on_gpu else None
         self.d_q = None
         self.q_local = None
+        self._shm = []
+        if gather == "host":
+            self._open_shared_host(nbuf)
+
+    # -- gather="host": the destination arrays in a shared, page-locked segment -----------------------
+    def _open_shared_host(self, nbuf: int):
+        """One POSIX shared-memory segment per buffer set: [rstat 8 B | rscor 24 B | flags 1 B] x rows_padded.  The
+        creator is the destination rank (rank 0 when every rank wants the rows); its name goes to the others through
+        the process group; every rank with a GPU registers the mapping with HIP so that its D2H copies are DMA."""
+        from multiprocessing import shared_memory
+        torch, dist, P = self.torch, self.dist, self.plan
+        owner = self.dst if self.dst is not None else 0
+        rows = P.rows_padded
+        self._host_views = []
+        for b in range(nbuf):
+            nbytes = rows * 33 + 64
+            names = [None]
+            if self.rank == owner:
+                seg = shared_memory.SharedMemory(create=True, size=nbytes)
+                names[0] = seg.name
+            if self.world > 1:
+                dist.broadcast_object_list(names, src=owner, group=self.group)
+            if self.rank != owner:
+                seg = shared_memory.SharedMemory(name=names[0])
+                try:        # attaching registers the segment with this process's resource tracker, which would unlink it
+                    from multiprocessing import resource_tracker      # (again) at exit: only the owner unlinks
+                    resource_tracker.unregister(seg._name, "shared_memory")
+                except Exception:
+                    pass
+            buf = np.frombuffer(seg.buf, dtype=np.uint8, count=rows * 33)
+            registered = False
+            if self.on_gpu or self.engine is not None:
+                rc = torch.cuda.cudart().cudaHostRegister(buf.ctypes.data, buf.nbytes, 0)
+                registered = int(rc) == 0
+            self._shm.append((seg, buf.ctypes.data, registered, self.rank == owner))
+            self._host_views.append((buf[:rows * 8], buf[rows * 8:rows * 32], buf[rows * 32:rows * 33]))
+        if self.world > 1:
+            dist.barrier(group=self.group)           # every rank has attached before the owner may ever unlink
+
+    def close(self):
+        """Release the shared host segments of gather="host" (no-op otherwise)."""
+        shm, self._shm = self._shm, []
+        self._host_views = []
+        for seg, ptr, registered, owner in shm:
+            try:
+                if registered:
+                    self.torch.cuda.synchronize()
+                    self.torch.cuda.cudart().cudaHostUnregister(ptr)
+            except Exception:
+                pass
+            try:
+                seg.close()
+                if owner:
+                    seg.unlink()
+            except Exception:
+                pass
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     # -- input ---------------------------------------------------------------------------------
     def set_quartets(self, quartets: np.ndarray):
@@ -244,6 +319,12 @@ class ShardedResolver:
         if s["done"] is not None or s["works"]:
             raise RuntimeError("buffer set still in flight: call finish() first")
         want_host = self._wants_host()
+        if self.gather == "host":
+            if self.world > 1:
+                dist.barrier(group=self.group)     # the destination is done with the rows of the previous batch in this segment
+            s["host"] = self._host_views[b] if want_host else None
+            self._start_host_gather(s, self._host_views[b], subsample_snps)
+            return
         if want_host:
             if self.on_gpu:
                 from .engine import pinned_empty
@@ -312,12 +393,62 @@ class ShardedResolver:
         else:
             s["done"] = True
 
+    def _start_host_gather(self, s, views, subsample_snps: bool):
+        """gather="host": kernels of the rank's parts, then its rows straight to their global positions in the shared
+        page-locked arrays (a part of a piece is the contiguous global row range part_range(i, rank))."""
+        torch, P = self.torch, self.plan
+        h_rstat, h_rscor, h_flags = (torch.from_numpy(v) for v in views)
+        if self.engine is not None:
+            cur = torch.cuda.current_stream(self.dev)
+            if self.n_local:
+                self.engine.scan_dev(self.d_q.data_ptr(), self.n_local, subsample_snps, cur.cuda_stream)
+        else:
+            rstat, rscor, flags = self.compute(self.q_local, subsample_snps) if self.n_local else (
+                np.zeros((0, 2), np.uint32), np.zeros((0, 3), np.float64), np.zeros(0, np.uint8))
+        for i in range(P.npieces):
+            p = P.part[i]
+            lo, hi = self.ranges[i]
+            n, off = hi - lo, int(self.offsets[i])
+            if not n:
+                continue
+            if self.engine is not None:
+                slab = s["slabs"][i]
+                base = slab.data_ptr()
+                self.engine.svd_dev(off, n, base, base + 8 * p, base + 32 * p, cur.cuda_stream)
+                self.side.wait_stream(cur)                     # the piece's kernels
+                with torch.cuda.stream(self.side):
+                    h_rstat[8 * lo:8 * hi].copy_(slab[:8 * n], non_blocking=True)
+                    h_rscor[24 * lo:24 * hi].copy_(slab[8 * p:8 * p + 24 * n], non_blocking=True)
+                    h_flags[lo:hi].copy_(slab[32 * p:32 * p + n], non_blocking=True)
+            else:
+                views[0][8 * lo:8 * hi] = np.ascontiguousarray(rstat[off:off + n], dtype=np.uint32).view(np.uint8).ravel()
+                views[1][24 * lo:24 * hi] = np.ascontiguousarray(rscor[off:off + n], dtype=np.float64).view(np.uint8).ravel()
+                views[2][lo:hi] = np.asarray(flags[off:off + n], dtype=np.uint8)
+        if self.engine is not None:
+            ev = torch.cuda.Event()
+            ev.record(self.side)
+            s["done"] = ev
+        else:
+            s["done"] = True
+
     def finish(self, b: int = 0):
         """Wait for set `b`; returns (rstat u32[Q,2], rscor f64[Q,3], flags u8[Q]) host arrays on the
         destination rank(s), (None, None, None) elsewhere."""
         s = self.sets[b]
         if s["done"] is None:
             raise RuntimeError("nothing in flight: call start() first")
+        if self.gather == "host":
+            if s["done"] is not True:
+                s["done"].synchronize()                        # this rank's own copies have landed ...
+            s["done"] = None
+            if self.world > 1:
+                self.dist.barrier(group=self.group)            # ... and so have everybody else's
+            host, s["host"] = s["host"], None
+            if host is None:
+                return None, None, None
+            Q = self.Q
+            return (host[0][:8 * Q].view(np.uint32).reshape(Q, 2), host[1][:24 * Q].view(np.float64).reshape(Q, 3),
+                    host[2][:Q])
         if self.on_gpu:
             s["done"].synchronize()
         s["done"] = None
@@ -336,9 +467,25 @@ class ShardedResolver:
         self.start(subsample_snps)
         return self.finish()
 
+    def local_rows(self, b: int = 0):
+        """This rank's OWN rows as they left its kernels (valid after finish, either gather mode), in the order of
+        plan.local_index(rank): (rstat int32[n,2], rscor f64[n,3], flags u8[n]) torch tensors on the compute device."""
+        s, P, torch = self.sets[b], self.plan, self.torch
+        a, c, f = [], [], []
+        for i in range(P.npieces):
+            lo, hi = self.ranges[i]
+            n, p = hi - lo, P.part[i]
+            slab = s["slabs"][i]
+            a.append(slab[:8 * n].view(torch.int32).view(n, 2))
+            c.append(slab[8 * p:8 * p + 24 * n].view(torch.float64).view(n, 3))
+            f.append(slab[32 * p:32 * p + n])
+        return torch.cat(a), torch.cat(c), torch.cat(f)
+
     def device_rows(self, b: int = 0):
         """The gathered batch in global order as it sits on this rank's gather device (valid after finish):
         (rstat int32[Q,2], rscor f64[Q,3], flags u8[Q]) torch views."""
+        if self.gather == "host":
+            raise RuntimeError("device_rows() needs gather='collective': with gather='host' no rank holds all rows on its device")
         s, Q, torch = self.sets[b], self.Q, self.torch
         return (s["all_rstat"][:8 * Q].view(torch.int32).view(Q, 2), s["all_rscor"][:24 * Q].view(torch.float64).view(Q, 3),
                 s["all_flags"][:Q])
@@ -349,14 +496,15 @@ _resolvers: dict = {}
 
 def resolve_sharded(tmparr, tmpmap, quartets, subsample_snps: bool = True, *, group=None,
                     compute: Optional[Callable] = None, device=None, dst: Optional[int] = None,
-                    pieces: Optional[int] = None):
+                    pieces: Optional[int] = None, gather: str = "collective"):
     """Resolve `quartets` (u32[Q,4], identical on every rank) across the ranks of `group`.
 
     Returns (quartets, rstat u32[Q,2], rscor f64[Q,3], flags u8[Q]), rows in the order of `quartets`,
     on every rank (`dst=None`) or on rank `dst` only (the other ranks get None for the three arrays: the
     reference's distributor consumes the rows on the client alone, run_inference.py:232-244).  With an
     uninitialised process group this is the 1-GPU path.  `compute(tmparr, tmpmap, quartets, subsample)`
-    replaces the HIP engine in CPU tests of the control flow."""
+    replaces the HIP engine in CPU tests of the control flow.  `gather="host"`: no collective, every rank copies its
+    rows into a shared page-locked host array (ShardedResolver); the arrays returned are then COPIES of that segment."""
     import torch
     import torch.distributed as dist
 
@@ -371,23 +519,31 @@ def resolve_sharded(tmparr, tmpmap, quartets, subsample_snps: bool = True, *, gr
         return quartets, np.zeros((0, 2), np.uint32), np.zeros((0, 3), np.float64), np.zeros(0, np.uint8)
     if compute is not None:
         res = ShardedResolver(Q, compute=lambda q, sub: compute(tmparr, tmpmap, q, sub), group=group, dst=dst,
-                              pieces=pieces)
+                              pieces=pieces, gather=gather)
     else:
         from .resolve_quartets import _ensure_resident, get_engine
         dev_id = torch.cuda.current_device() if device is None else torch.device(device).index
         eng = get_engine(dev_id)
         _ensure_resident(eng, tmparr, tmpmap)
-        key = (Q, world, dev_id, dst, pieces)
+        key = (Q, world, dev_id, dst, pieces, gather)
         res = _resolvers.get("res") if _resolvers.get("key") == key else None
         # the cached resolver is only good for the SAME live engine and process group objects (an id() can be
         # re-used by a new group after the old one is destroyed; get_engine may hand out a fresh engine after close)
         if res is not None and not (res.engine is eng and res.group is group):
             res = None
         if res is None:                                  # buffers are kept for the next batch of this size
-            res = ShardedResolver(Q, engine=eng, group=group, device=dev_id, dst=dst, pieces=pieces)
+            old = _resolvers.get("res")
+            if old is not None:
+                old.close()
+            res = ShardedResolver(Q, engine=eng, group=group, device=dev_id, dst=dst, pieces=pieces, gather=gather)
             _resolvers.update(key=key, res=res)
     res.set_quartets(quartets)
     rstat, rscor, flags = res.resolve(subsample_snps)
+    if gather == "host":
+        if rstat is not None:                            # views of the shared segment: hand out copies
+            rstat, rscor, flags = rstat.copy(), rscor.copy(), flags.copy()
+        if compute is not None:
+            res.close()
     return quartets, rstat, rscor, flags
 
 

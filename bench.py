@@ -895,7 +895,7 @@ def bench_c5(args, eng, torch, dist, dev, world, rank):
     T, S0 = seqarr.shape
     Q = args.quartets or 1_000_000
     runner = ReplicateRunner(eng, seqarr, spans, Q, seed=synth.CONFIG_SEEDS["c5"], sampler=args.sampler,
-                             pieces=args.pieces or None)
+                             pieces=args.pieces or None, gather=args.gather)
     sub = not args.full
     for _ in range(args.warmup):
         runner.run(1, sub)

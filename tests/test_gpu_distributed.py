@@ -47,7 +47,8 @@ from tetrad_amd.replicates import ReplicateRunner
 seqarr, maparr, spans = synth.make_c5_source(T=14, S=6000, seed=8, ambiguous=0.02)
 for sampler in ("host", "device"):
     got = {}
-    runner = ReplicateRunner(get_engine(0), seqarr, spans, 701, seed=5, sampler=sampler, pieces=2)
+    runner = ReplicateRunner(get_engine(0), seqarr, spans, 701, seed=5, sampler=sampler, pieces=2,
+                             gather=("host" if sampler == "device" else "collective"))
     runner.run(3, True, on_result=lambda k, S, a, b, c: got.__setitem__(k, (a.copy(), b.copy(), c.copy())))
     runner.close()
     if rank == 0:

@@ -44,7 +44,8 @@ from .engine import QuartetEngine, pinned_empty
 class ReplicateRunner:
     def __init__(self, engine: QuartetEngine, seqarr: np.ndarray, spans: np.ndarray, nquartets: int, *,
                  seed=None, rng: Optional[np.random.Generator] = None, sampler: str = "host", group=None,
-                 pieces: Optional[int] = None, dst: Optional[int] = 0, ahead: int = 3, quartets_to_host: bool = False):
+                 pieces: Optional[int] = None, dst: Optional[int] = 0, ahead: int = 3, quartets_to_host: bool = False,
+                 gather: str = "collective"):
         import torch
         if sampler not in ("host", "device"):
             raise ValueError("sampler must be 'host' or 'device'")
@@ -59,7 +60,8 @@ class ReplicateRunner:
         self.Q = int(nquartets)
         if self.Q > self.total:
             raise ValueError(f"cannot sample {self.Q} of {self.total} quartets")
-        self.res = ShardedResolver(self.Q, engine=engine, group=group, pieces=pieces, dst=dst, nbuf=2)
+        # gather="host": the rows handed to on_result are views of a shared segment, valid until the replicate after next
+        self.res = ShardedResolver(self.Q, engine=engine, group=group, pieces=pieces, dst=dst, nbuf=2, gather=gather)
         self.n_local = self.res.n_local
         self.ranges = self.res.ranges
         self.dev = self.res.dev
@@ -195,6 +197,7 @@ class ReplicateRunner:
         self._stop.set()
         if self._thread is not None:
             self._thread.join()
+        self.res.close()
 
 
 def bootstrap_trees(engine: QuartetEngine, seqarr: np.ndarray, spans: np.ndarray, nquartets: int, nboots: int, *,

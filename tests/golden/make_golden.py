@@ -108,8 +108,49 @@ def loci_map(S, rng, mean=4):
     return tmap
 
 
+def make_slices(ref):
+    # (10) slices of c2 / c3 / c4 shaped inputs are regenerated from the seed on the fly by
+    #      the tests (inputs are deterministic); only the reference outputs for a sample of
+    #      quartets are stored here (round 4: 128 / 96 / 48 quartets, 24 / 12 / 12 before).
+    for cfg, nq in (("c2", 128), ("c3", 96), ("c4", 48)):
+        T, S, _ = synth.CONFIGS[cfg]
+        arr, tmap = synth.simulate_tmparr(T, S, synth.CONFIG_SEEDS[cfg])
+        qrts = synth.random_quartets(T, nq, seed=777)
+        blob = dict(quartets=qrts, config=np.array(cfg), numpy_version=np.array(np.__version__))
+        for sub in (False, True):
+            res = run_reference(ref, arr, tmap, qrts, sub, with_cmats=True)
+            tag = "sub" if sub else "full"
+            for k, v in res.items():
+                blob[f"{tag}_{k}"] = v
+        np.savez_compressed(OUT / f"{cfg}_slice.npz", **blob)
+        print(f"wrote {cfg}_slice.npz  Q={nq}")
+
+
+def make_rows(ref):
+    # (12) the reference worker's ROWS (rstat, rscor; no count matrices) for thousands of quartets of the c2 / c3 / c4
+    #      benchmark inputs: the bulk parity evidence at benchmark size straight from the reference
+    for cfg, nq in (("c2", 3000), ("c3", 2000), ("c4", 1000)):
+        T, S, _ = synth.CONFIGS[cfg]
+        arr, tmap = synth.simulate_tmparr(T, S, synth.CONFIG_SEEDS[cfg])
+        qrts = synth.random_quartets(T, nq, seed=4321)
+        blob = dict(quartets=qrts, config=np.array(cfg), numpy_version=np.array(np.__version__))
+        for sub in (False, True):
+            res = run_reference(ref, arr, tmap, qrts, sub, with_cmats=False)
+            tag = "sub" if sub else "full"
+            for k, v in res.items():
+                blob[f"{tag}_{k}"] = v
+        np.savez_compressed(OUT / f"{cfg}_rows.npz", **blob)
+        print(f"wrote {cfg}_rows.npz  Q={nq}")
+
+
 def main(only=None):
     ref = load_reference()
+    if only == "rows":
+        make_rows(ref)
+        return
+    if only == "slices":
+        make_slices(ref)
+        return
     if only == "minrank_T14_S600":          # (11) alone: the other fixtures are unchanged (they reproduce bit for bit)
         arr, tmap = synth.simulate_tmparr(14, 600, seed=9, p=0.01, missing=0.3)
         save("minrank_T14_S600", arr, tmap, synth.all_quartets(14), ref)
@@ -171,21 +212,8 @@ def main(only=None):
     arr, tmap, qrts = synth.make_config("c1")
     save("c1_T16_S5000", arr, tmap, qrts, ref, with_cmats=False)
 
-    # (10) slices of c2 / c3 / c4 shaped inputs are regenerated from the seed on the fly by
-    #      the tests (inputs are deterministic); only the reference outputs for a few
-    #      quartets are stored here.
-    for cfg, nq in (("c2", 24), ("c3", 12), ("c4", 12)):
-        T, S, _ = synth.CONFIGS[cfg]
-        arr, tmap = synth.simulate_tmparr(T, S, synth.CONFIG_SEEDS[cfg])
-        qrts = synth.random_quartets(T, nq, seed=777)
-        blob = dict(quartets=qrts, config=np.array(cfg), numpy_version=np.array(np.__version__))
-        for sub in (False, True):
-            res = run_reference(ref, arr, tmap, qrts, sub, with_cmats=True)
-            tag = "sub" if sub else "full"
-            for k, v in res.items():
-                blob[f"{tag}_{k}"] = v
-        np.savez_compressed(OUT / f"{cfg}_slice.npz", **blob)
-        print(f"wrote {cfg}_slice.npz")
+    make_slices(ref)
+    make_rows(ref)
 
 
 def load_reference_jitted():
@@ -247,7 +275,7 @@ def make_c5_golden():
     tmparr[tmparr == 67] = 1
     tmparr[tmparr == 71] = 2
     tmparr[tmparr == 84] = 3
-    qrts = synth.random_quartets(seqarr.shape[0], 12, seed=778)
+    qrts = synth.random_quartets(seqarr.shape[0], 96, seed=778)
     blob = dict(quartets=qrts, lidxs=lidxs, seed_resample=np.array(seed1), seed_ambig=np.array(seed2),
                 replicate_shape=np.array(tmparr.shape), replicate_crc32=np.array(zlib.crc32(tmparr.tobytes())),
                 tmpmap_crc32=np.array(zlib.crc32(np.ascontiguousarray(tmpmap).tobytes())),
@@ -267,6 +295,10 @@ if __name__ == "__main__":
         main()
     if "minrank" in which:
         main(only="minrank_T14_S600")
+    if "slices" in which:
+        main(only="slices")
+    if "rows" in which:
+        main(only="rows")
     if "resample" in which:
         make_resample_golden()
     if "c5" in which:

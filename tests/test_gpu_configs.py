@@ -112,7 +112,7 @@ def _c5_reference_replicate():
 
 
 def test_c5_reference_replicate_slice(engine):
-    """c5 shape: a bootstrap replicate made by the reference's own resampler, reference outputs for 12 quartets."""
+    """c5 shape: a bootstrap replicate made by the reference's own resampler, reference outputs for 96 quartets."""
     g, _, _, tmparr, tmpmap = _c5_reference_replicate()
     engine.set_data(tmparr, tmpmap)
     for mode in ("full", "sub"):

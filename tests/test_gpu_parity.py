@@ -101,6 +101,22 @@ def test_config_slices(engine, cfg):
         assert ndeg == 0
 
 
+@pytest.mark.parametrize("cfg", ["c2", "c3", "c4"])
+def test_reference_rows_at_benchmark_size(engine, cfg):
+    """The REFERENCE worker's rows for 3 000 (c2) / 2 000 (c3) / 1 000 (c4) random quartets of the benchmark inputs
+    (`c*_rows.npz`, made by the reference itself): site counts exact, scores within tolerance, topology exact on every row
+    that neither the reference's scores nor the device flag as noise-decided -- and none is, on these inputs."""
+    from tetrad_amd import synth
+    g = load_golden(f"{cfg}_rows")
+    T, S, _ = synth.CONFIGS[cfg]
+    tmparr, tmpmap = synth.simulate_tmparr(T, S, synth.CONFIG_SEEDS[cfg])
+    engine.set_data(tmparr, tmpmap)
+    for mode in ("full", "sub"):
+        rstat, rscor, flags = engine.resolve(g["quartets"], mode == "sub")
+        nok, ndeg = check_against(g, mode, rstat, rscor, flags, None)
+        assert ndeg == 0 and nok == len(g["quartets"])
+
+
 @pytest.mark.parametrize("seed,T,S,missing,p", [(21, 20, 3000, 0.1, 0.05), (22, 9, 4097, 0.5, 0.02),
                                                  (23, 30, 2048, 0.0, 0.2), (24, 6, 65, 0.2, 0.1)])
 def test_seeded_vs_oracle(engine, oracle, seed, T, S, missing, p):

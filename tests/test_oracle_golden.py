@@ -95,6 +95,20 @@ def test_oracle_matches_reference_on_config_slices(oracle, cfg):
         np.testing.assert_array_equal(rscor, g[f"{mode}_rscor"])
 
 
+@pytest.mark.parametrize("cfg,n", [("c2", 300), ("c3", 150), ("c4", 60)])
+def test_oracle_matches_reference_rows_at_benchmark_size(oracle, cfg, n):
+    """`c{2,3,4}_rows.npz`: the reference worker's rows for 3 000 / 2 000 / 1 000 quartets of the benchmark inputs (the GPU
+    test compares all of them with the device); the oracle is checked on the first n of each here (CPU time)."""
+    from tetrad_amd import synth
+    g = load_golden(f"{cfg}_rows")
+    T, S, _ = synth.CONFIGS[cfg]
+    tmparr, tmpmap = synth.simulate_tmparr(T, S, synth.CONFIG_SEEDS[cfg])
+    for mode in ("full", "sub"):
+        _, rstat, rscor = oracle.new_infer_resolved_quartets(tmparr, tmpmap, g["quartets"][:n], mode == "sub")
+        np.testing.assert_array_equal(rstat, g[f"{mode}_rstat"][:n])
+        np.testing.assert_array_equal(rscor, g[f"{mode}_rscor"][:n])
+
+
 def test_oracle_matches_reference_on_c5_replicate(oracle):
     """BASELINE.json configs[4]: the bootstrap replicate the reference's resampler made from the c5 source is
     rebuilt by the oracle's restatement (CRC-checked), and the oracle worker reproduces the reference's rows."""

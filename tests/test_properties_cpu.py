@@ -58,3 +58,49 @@ def test_spans_partition_the_sites(S, seed):
     assert sp[0, 0] == 0 and sp[-1, 1] == S and (sp[1:, 0] == sp[:-1, 1]).all() and (sp[:, 1] > sp[:, 0]).all()
     if len(np.unique(loc)) > 1:
         np.testing.assert_array_equal(sp, R.get_spans(m))
+
+
+def test_hdf5_branch_of_load_database_with_a_stand_in_h5py(tmp_path, monkeypatch):
+    """`infer_resolved_quartets` opens the reference's database as `h5py.File(path, 'r', swmr=True)` and reads the
+    datasets `tmparr` / `tmpmap` whole (resolve_quartets.py:33-35).  h5py is not installed in this image, so the branch
+    is exercised with a stand-in module that accepts exactly that call shape and serves the arrays of an .npz kept
+    beside the .hdf5 path (the loader's own logic -- suffix dispatch, caching on (path, mtime, size), the replicate token
+    -- is what is under test; no compute call, so no GPU)."""
+    import sys
+    import types
+    calls = []
+
+    class File:
+        def __init__(self, path, mode, swmr=False):
+            calls.append((str(path), mode, swmr))
+            self._z = np.load(str(path) + ".npz", allow_pickle=False)
+
+        def __enter__(self):
+            return self
+
+        def __exit__(self, *exc):
+            self._z.close()
+
+        def __getitem__(self, name):
+            return self._z[name]
+
+    fake = types.ModuleType("h5py")
+    fake.File = File
+    monkeypatch.setitem(sys.modules, "h5py", fake)
+    from tetrad_amd import resolve_quartets as RQ
+    rng = np.random.default_rng(3)
+    tmparr = rng.integers(0, 4, size=(6, 500), dtype=np.uint8)
+    tmpmap = np.stack([np.arange(500) // 5, np.arange(500)], axis=1).astype(np.uint32)
+    db = tmp_path / "proj.snps.hdf5"
+    db.write_bytes(b"\x89HDF\r\n\x1a\n")                     # the path must exist: the cache key is (path, mtime, size)
+    np.savez(str(db) + ".npz", tmparr=tmparr, tmpmap=tmpmap)
+    monkeypatch.setattr(RQ, "_db_cache", {})
+    a, m, token = RQ.load_database(db, with_token=True)
+    np.testing.assert_array_equal(a, tmparr)
+    np.testing.assert_array_equal(m, tmpmap)
+    assert calls == [(str(db), "r", True)]
+    a2, m2, token2 = RQ.load_database(db, with_token=True)    # second chunk of the same replicate: cached, same token
+    assert a2 is a and token2 == token and len(calls) == 1
+    db.write_bytes(b"\x89HDF\r\n\x1a\n" + b"x")               # the file changed (next replicate): read again, new token
+    a3, _, token3 = RQ.load_database(db, with_token=True)
+    assert token3 != token and len(calls) == 2

@@ -328,7 +328,9 @@ def parse_args(argv=None):
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo = rehearsal of the N>1 control flow on a box with fewer GPUs than ranks")
     ap.add_argument("--pieces", type=int, default=0, help="N > 1: result pieces per batch (0 = automatic)")
-    ap.add_argument("--no-gather-ab", action="store_true", help="N > 1: skip the short leg with the other --gather mode")
+    ap.add_argument("--gather-ab", action="store_true",
+                    help="N > 1: add a three-step leg with the OTHER --gather mode to the line (other_gather_leg); opt-in, so that "
+                         "the bare command a driver runs on a multi-GPU node exercises one data path only")
     ap.add_argument("--gather", default="collective", choices=["collective", "host"],
                     help="N > 1: 'collective' = one all-gather per piece, rank 0 copies the rows D2H (default); 'host' = every "
                          "rank copies its own rows D2H into rank 0's shared page-locked arrays, no collective on the data path")
@@ -752,7 +754,7 @@ def main(argv=None):
                                         else "the whole batch (strong scaling: ideal = n_gpus)"))
         # the same workload with the OTHER way of getting the rows to rank 0 (a few steps, same run): one of the two A/Bs
         # DESIGN.md section 6 wants measured on a multi-GPU node before either is trusted as the default
-        if not args.no_gather_ab:
+        if args.gather_ab:
             other = "host" if args.gather == "collective" else "collective"
             ro = run_sharded(wl, min(args.steps, 3), 1, timing=False, gather=other, with_one_gpu=False)
             if rank == 0:

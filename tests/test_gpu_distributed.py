@@ -125,11 +125,13 @@ def test_bare_bench_command_runs_two_ranks():
     assert d["n_gpus"] == 2 and d["scaling"] == "weak"
     # the same with --gather host (no collective on the data path)
     r = subprocess.run([sys.executable, str(REPO / "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "2",
-                        "--warmup", "1", "--quartets", "40000", "--gather", "host", "--no-c4-leg"], capture_output=True,
+                        "--warmup", "1", "--quartets", "40000", "--gather", "host", "--no-c4-leg", "--gather-ab"], capture_output=True,
                        text=True, env=env, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     d = json.loads([ln for ln in r.stdout.splitlines() if ln.strip()][0])
     assert d["n_gpus"] == 2 and d["gather_verified"] and d["one_gpu_rows_equal_gathered_rows"]
+    leg = d["other_gather_leg"]
+    assert leg["gather"] == "collective" and leg["gather_verified"] and leg["rows_equal_main_leg"]
     assert d["config"]["quartets"] == 80000                      # weak: every rank its own 40 000
     assert d["gather_verified"] is True
     assert d["one_gpu_rows_equal_gathered_rows"] is True

@@ -26,6 +26,8 @@ from __future__ import annotations
 from pathlib import Path
 from typing import Callable, Iterable, Optional
 
+import os
+
 import numpy as np
 
 MIN_PART_ROWS = 300_000        # a rank's part of a piece is at least this many quartets: stage_svd cuts a part into two half-chunks
@@ -226,10 +228,23 @@ class ShardedResolver:
             nbytes = rows * 33 + 64
             names = [None]
             if self.rank == owner:
-                seg = shared_memory.SharedMemory(create=True, size=nbytes)
-                names[0] = seg.name
+                # a segment larger than what /dev/shm can hold is created without complaint and kills the first process
+                # that writes past the limit (SIGBUS): check before creating, and tell every rank the same thing
+                try:
+                    st = os.statvfs("/dev/shm")
+                    room = st.f_bavail * st.f_frsize
+                except OSError:
+                    room = None
+                if room is not None and room < nbytes + (16 << 20):
+                    names[0] = f"!/dev/shm has {room >> 20} MiB free, the result segment needs {nbytes >> 20} MiB"
+                else:
+                    seg = shared_memory.SharedMemory(create=True, size=nbytes)
+                    names[0] = seg.name
             if self.world > 1:
                 dist.broadcast_object_list(names, src=owner, group=self.group)
+            if names[0] is None or names[0].startswith("!"):
+                self.close()
+                raise RuntimeError("gather='host': " + (names[0] or "no segment")[1:])
             if self.rank != owner:
                 seg = shared_memory.SharedMemory(name=names[0])
                 try:        # attaching registers the segment with this process's resource tracker, which would unlink it

@@ -31,8 +31,8 @@ echo configs done
 python3 bench.py --config c5 --steps 100 --warmup 2 > $O/bench_c5_100_host_sampler.json 2> /dev/null
 python3 bench.py --config c5 --steps 100 --warmup 2 --sampler device > $O/bench_c5_100_device_sampler.json 2> /dev/null
 echo c5 done
-python3 bench.py --gpus 2 --backend gloo --steps 3 --warmup 1 > $O/bench_two_rank_gloo_rehearsal_bare_command.json 2> $O/gloo.err
-python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 1 --sharded --steps 3 --warmup 1 > $O/bench_sharded_one_rank_rccl.json 2> $O/rccl.err || true
+python3 bench.py --gpus 2 --backend gloo --steps 3 --warmup 1 --gather-ab > $O/bench_two_rank_gloo_rehearsal_bare_command.json 2> $O/gloo.err
+python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 1 --sharded --steps 3 --warmup 1 --gather-ab > $O/bench_sharded_one_rank_rccl.json 2> $O/rccl.err || true
 for i in 1 2 3; do python3 bench.py --no-cpu --steps 10 --warmup 2 | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'])"; done > $O/repeatability.txt
 ls -la $O
 head -c 900 $O/kernel_stats.csv

@@ -210,7 +210,8 @@ int tq_timing_read_kernels(tq_ctx *ctx, double *ms, int n_ms, int64_t *calls);
 /* Tuning / diagnostic knobs (value 0 = library default unless noted).  Returns TQ_OK or an error.
  * Names: nrep, waves_per_cu, batch (quartets per internal batch, default 2^23; device scratch is about
  * 3.2 KB per quartet of the largest batch resolved so far), order, scan_wg (waves per scan workgroup: 1, 2, 4, 8, 16), scan_method (-1 auto), svd_method (0 Jacobi,
- * 1 Householder+QR), xcd_remap (1: scan workgroups of one XCD take a contiguous part of the sorted order),
+ * 1 Householder+QR), bidiag_layout (1, default: the bidiagonalisation deals a matrix 2 x 2 over four lanes; 0: four column
+ * groups), xcd_remap (1: scan workgroups of one XCD take a contiguous part of the sorted order),
  * svd_wpc (blocks per CU of the singular-value grids, 0 = one pass per block), svd_chunk (quartets per
  * pass of the singular-value stage = per result-copy piece, default 2^18), svd_streams (1 or 2: chunks alternate
  * between two streams so that one chunk's tail is filled by the next chunk; default 2), share_c (1: scan variant that also shares row c inside a

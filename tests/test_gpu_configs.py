@@ -386,3 +386,28 @@ def test_device_api_calls_on_different_streams_and_host_api_are_ordered(oracle):
             _, o_rstat, o_rscor = oracle.new_infer_resolved_quartets(tmparr, tmpmap, q, sub)
             np.testing.assert_array_equal(rstat[:, 1], o_rstat[:, 1])
             np.testing.assert_allclose(rscor, o_rscor, rtol=1e-6, atol=1e-9)
+
+
+def test_debug_bdsqr_hook_reproduces_the_pipeline_values():
+    """`tq_debug_bdsqr` (tools/bdsqr_order.py measures wave orderings with it) runs the QR kernel alone on bidiagonals
+    given on the host: on the bidiagonals the pipeline itself left behind it must return the pipeline's own singular
+    values, bit for bit, in the given order and in a permuted one (a lane's arithmetic does not depend on its wave-mates),
+    together with plausible work counters."""
+    from tetrad_amd import synth
+    from tetrad_amd.engine import QuartetEngine
+    tmparr, tmpmap = synth.simulate_tmparr(20, 6000, 13)
+    q = synth.random_quartets(20, 3000, seed=4)
+    with QuartetEngine(0) as eng:
+        eng.set_data(tmparr, tmpmap)
+        eng.set_option("svd_streams", 1)
+        eng.set_option("svd_chunk", len(q))
+        eng.resolve(q, True)
+        de = eng.debug_fetch("de", len(q))
+        sv_pipe = eng.debug_fetch("sv", len(q))
+        sv, steps, sweeps, ms = eng.debug_bdsqr(de, reps=2)
+        np.testing.assert_array_equal(sv, sv_pipe)
+        assert ms > 0 and steps.min() >= 15 and steps.max() < 2000 and sweeps.min() >= 1
+        perm = np.random.default_rng(0).permutation(len(de))
+        sv_p, steps_p, _, _ = eng.debug_bdsqr(de[perm], reps=1)
+        np.testing.assert_array_equal(sv_p, sv[perm])
+        np.testing.assert_array_equal(steps_p, steps[perm])

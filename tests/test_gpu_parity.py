@@ -20,10 +20,14 @@ ATOL_REL_SMAX = 1e-12
 @pytest.fixture(scope="module", params=["hqr", "jacobi"])
 def engine(request):
     """Every parity test runs against both device SVD paths: Householder + bidiagonal QR
-    (default) and one-sided Jacobi."""
+    (default) and one-sided Jacobi -- and against both scan kernels: the "hqr" engine sends every batch of 64 quartets or
+    more to the cooperative workgroup kernel (the default threshold is 2 048: smaller calls are latency-bound and go to the
+    one-wave-per-quartet kernel), the "jacobi" engine keeps the default, so the small golden cases cover both."""
     from tetrad_amd.engine import QuartetEngine
     eng = QuartetEngine(0)
     eng.set_option("svd_method", 1 if request.param == "hqr" else 0)
+    if request.param == "hqr":
+        eng.set_option("wg_min_quartets", 64)
     yield eng
     eng.close()
 

@@ -120,6 +120,10 @@ struct tq_ctx {
     uint64_t *d_bdsqr_stats = nullptr;   // diagnostics (option "bdsqr_stats"): {matrices, rotation steps of all lanes,
                                          // lane-slots issued (64 x wave iterations), sweeps} summed over the launches
     int scan_wg = 4;                // waves per workgroup of the cooperative scan kernel (1 = one wave per quartet)
+    int64_t wg_min_quartets = 2048; // smaller batches go to the one-wave-per-quartet kernel: a call of a thousand quartets does not
+                                    // fill the chip and is bound by the latency of one quartet's 25 dependent steps, which the
+                                    // cooperative kernel's per-step barrier and image hand-over only lengthen (1 000 random
+                                    // quartets 0.179 -> 0.163 ms per call; the cooperative kernel wins from ~8 000 on)
     int xcd_remap = 1;              // 1: scan workgroups of one XCD take a contiguous part of the sorted order
     int count_invariant = 0;        // 1: invariant sites (all four bases equal, none missing) are counted as well -- what the reference's
                                     // count kernels do when their caller's mask leaves such a site open (resolve_quartets.py:59-64);
@@ -558,7 +562,8 @@ int launch_scan_n(tq_ctx *ctx, const uint32_t *dq, const uint32_t *order, int64_
                          (uint64_t)ctx->T * (uint64_t)ctx->Sp < 0xFFFF0000ull;
     if (pb_fits && ctx->scan_method == 6)
         return subsample ? launch_scan_pb<true>(ctx, dq, order, Q, stream) : launch_scan_pb<false>(ctx, dq, order, Q, stream);
-    if (ctx->scan_wg >= 2 && Q >= 64 && !ctx->count_invariant && (uint64_t)ctx->T * (uint64_t)ctx->Sp < 0xFFFF0000ull) {
+    if (ctx->scan_wg >= 2 && Q >= ctx->wg_min_quartets && !ctx->count_invariant &&
+        (uint64_t)ctx->T * (uint64_t)ctx->Sp < 0xFFFF0000ull) {
         int m = ctx->scan_method < 0 ? (subsample ? 1 : 0) : ctx->scan_method;
         if (m == 6) m = subsample ? 1 : 0;
 #define TQ_WG_CASE(NW)                                                                                   \
@@ -1438,6 +1443,11 @@ int tq_set_option(tq_ctx *ctx, const char *name, int64_t value)
     }
     if (!strcmp(name, "scan_pair")) {
         ctx->scan_pair = value != 0;
+        return TQ_OK;
+    }
+    if (!strcmp(name, "wg_min_quartets")) {
+        if (value < 0) return fail(ctx, TQ_ERR_INVALID_ARG, "wg_min_quartets must be >= 0");
+        ctx->wg_min_quartets = value ? value : 2048;
         return TQ_OK;
     }
     if (!strcmp(name, "bidiag_layout")) {

@@ -11,6 +11,10 @@ T, S, _ = synth.CONFIGS["c3"]
 tmparr, tmpmap = synth.simulate_tmparr(T, S, 103)
 q = synth.random_quartets(T, 200_000, 4242)
 eng = QuartetEngine(0); eng.set_data(tmparr, tmpmap)
+for kv in sys.argv[3:]:                     # engine options, name=value
+    k, v = kv.split("=")
+    eng.set_option(k, int(v))
+    print("option", k, v)
 for sub in (True, False):
     for _ in range(5):
         eng.resolve(q[:n], sub)

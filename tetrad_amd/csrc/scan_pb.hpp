@@ -1,8 +1,13 @@
-// scan_pb.hpp -- site scan with BANK-PRIVATE histograms (the default of full mode, subsample_snps=False:
-// resolve_quartets.py:76-104 -- the reference's default, cli_init.py:61).
+// scan_pb.hpp -- site scan with BANK-PRIVATE histograms: an A/B form of the scan (tq_set_option "scan_method" 6), built for
+// full mode (subsample_snps=False: resolve_quartets.py:76-104 -- the reference's default, cli_init.py:61).
+// MEASURED SLOWER THAN tq_scan_wg_kernel<false,0,4> AND OFF BY DEFAULT (c3 full mode 11.1 ms against 9.1; DESIGN.md 4.1,
+// profiles/r04_scan/): it removes the bank conflicts it was built to remove (SQ_LDS_BANK_CONFLICT -97 %), but a conflict-free
+// ds_add_u32 still costs a CU the 4.2 cycles its two source registers take to reach the LDS (tools/probe_slots.hip), only 23 %
+// under the shared-bin form, and the 64 KiB of counters leave two workgroups per CU.  Parity-tested like every other form
+// (tests/test_gpu_configs.py, the fuzz).
 // Part of the single translation unit tetrad_hip.hip (included inside its anonymous namespace, after scan.hpp).
 //
-// Why.  Full mode counts 12.8 of a lane's 32 sites per 2048-site step (c3).  tq_scan_wg_kernel<false,0,4> issues one
+// Why it was built.  Full mode counts 12.8 of a lane's 32 sites per 2048-site step (c3).  tq_scan_wg_kernel<false,0,4> issues one
 // EXEC-masked ds_add_u32 per site slot into a 256-bin histogram per wave: 32 atomics per step at 40 % lane occupancy,
 // 13 random bins per 32-lane group into 32 banks = the birthday bound, 2.3 LDS cycles per group where 1 is the floor
 // (profiles/r03_scan/full_mode_method0.txt: SQ_LDS_IDX_ACTIVE 77 % of the CU-busy cycles, half of it conflicts; the

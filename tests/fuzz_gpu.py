@@ -42,7 +42,8 @@ while time.time() < t_end:
             "svd_method": int(rng.choice([1, 1, 0])), "xcd_remap": int(rng.integers(2)),
             "svd_chunk": int(rng.choice([0, 0, 1, 100, 1024])), "svd_streams": int(rng.choice([0, 0, 1])),
             "share_c": int(rng.choice([0, 0, 1])), "park_t": int(rng.choice([1, 1, 0])), "scan_pair": int(rng.choice([0, 0, 1])),
-            "scan_method": int(rng.choice([-1, -1, 0, 1, 6])), "bidiag_layout": int(rng.choice([1, 1, 0])), "wg_min_quartets": int(rng.choice([0, 64, 64]))}
+            "scan_method": int(rng.choice([-1, -1, 0, 1, 6])), "bidiag_layout": int(rng.choice([1, 1, 0])), "wg_min_quartets": int(rng.choice([0, 64, 64])),
+            "scan_dp": int(rng.choice([1, 1, 0])), "dp_min_quartets": int(rng.choice([0, 2, 2, 500]))}
     for k, v in opts.items():
         eng.set_option(k, v)
     eng.set_data(tmparr, tmpmap)

@@ -238,13 +238,14 @@ def test_scan_kernel_variants_agree_on_sorted_batches(cfg, nq):
     T, S, _ = synth.CONFIGS[cfg]
     tmparr, tmpmap = synth.simulate_tmparr(T, S, synth.CONFIG_SEEDS[cfg])
     q = synth.all_quartets(T)[:nq] if cfg == "c2" else synth.random_quartets(T, nq, seed=5)
-    defaults = {"park_t": 1, "scan_pair": 0, "share_c": 0, "scan_wg": 0, "scan_method": -1}
+    defaults = {"park_t": 1, "scan_pair": 0, "share_c": 0, "scan_wg": 0, "scan_method": -1, "scan_dp": 1}
     with QuartetEngine(0) as eng:
         eng.set_data(tmparr, tmpmap)
         for sub in (True, False):
             base = eng.resolve(q, sub)
             for opts in ({"park_t": 0}, {"scan_pair": 1}, {"scan_pair": 1, "scan_method": 1 - int(sub)}, {"share_c": 1},
-                         {"scan_wg": 8}, {"scan_method": 1 - int(sub)}, {"scan_method": 6}, {"scan_method": int(sub)}):
+                         {"scan_wg": 8}, {"scan_method": 1 - int(sub)}, {"scan_method": 6}, {"scan_method": int(sub)},
+                         {"scan_dp": 0}):
                 for k, v in opts.items():
                     eng.set_option(k, v)
                 got = eng.resolve(q, sub)
@@ -252,6 +253,69 @@ def test_scan_kernel_variants_agree_on_sorted_batches(cfg, nq):
                     eng.set_option(k, defaults[k])
                 for a, b in zip(base, got):
                     np.testing.assert_array_equal(a, b, err_msg=f"{opts} sub={sub}")
+
+
+def test_joint_histogram_scan_on_messy_batches(oracle):
+    """scan_dp.hpp (full mode: two quartets that share (a,b,c) per wave, one joint histogram, folded at the end) against
+    the one-quartet kernels and the oracle on what a caller may hand over: repeated quartets (runs of equal keys of any
+    length), taxa in any order, taxon indices out of range, an all-missing taxon, quartets that arrive sorted or not,
+    ordering switched off (then the kernel must not be chosen: its pairing relies on sorted keys)."""
+    from tetrad_amd import synth
+    from tetrad_amd.engine import QuartetEngine
+    rng = np.random.default_rng(17)
+    T, S = 21, 4500
+    tmparr, tmpmap = synth.simulate_tmparr(T, S, 99, p=0.08, missing=0.3)
+    tmparr[5] = 78
+    q = np.stack([rng.permutation(T)[:4] for _ in range(6000)]).astype(np.uint32)         # unsorted taxa, many repeats of (a,b,c)
+    q[rng.integers(0, len(q), 300)] = q[0]                                                # one long run of equal quartets
+    q[10:20] = np.sort(q[10:20], axis=1)
+    bad = q.copy()
+    bad[7, 3] = T + 3
+    bad[8, 0] = 4_000_000_000
+    with QuartetEngine(0) as eng:
+        eng.set_data(tmparr, tmpmap)
+        eng.set_option("dp_min_quartets", 2)
+        for quartets in (q, q[np.lexsort((q[:, 3], q[:, 2], q[:, 1], q[:, 0]))], q[:1], q[:2], q[:5]):
+            eng.set_option("scan_dp", 1)
+            got = eng.resolve(quartets, False, debug=True)
+            eng.set_option("scan_dp", 0)
+            want = eng.resolve(quartets, False, debug=True)
+            np.testing.assert_array_equal(got[3]["cmats"], want[3]["cmats"])
+            for a, b in zip(got[:3], want[:3]):
+                np.testing.assert_array_equal(a, b)
+        _, o_rstat, _, o = oracle.new_infer_resolved_quartets(tmparr, tmpmap, q[:400], False, debug=True)
+        eng.set_option("scan_dp", 1)
+        got = eng.resolve(q[:400], False, debug=True)
+        np.testing.assert_array_equal(got[3]["cmats"], o["cmats"])
+        np.testing.assert_array_equal(got[0][:, 1], o_rstat[:, 1])
+        # taxon indices out of range (the device API does not look at the indices on the host): those rows are flagged
+        # TQ_FLAG_BAD_INDEX by both kernels, the other rows are what they are without them
+        import torch
+        dev = torch.device("cuda:0")
+        dq = torch.from_numpy(bad.astype(np.int64)).to(dev).to(torch.int32)               # (values >= 2^31 wrap: same bits)
+        outs = []
+        for dp in (1, 0):
+            eng.set_option("scan_dp", dp)
+            drs = torch.zeros((len(bad), 2), dtype=torch.int32, device=dev)
+            dsc = torch.zeros((len(bad), 3), dtype=torch.float64, device=dev)
+            dfl = torch.zeros(len(bad), dtype=torch.uint8, device=dev)
+            eng.resolve_dev(dq.data_ptr(), len(bad), False, drs.data_ptr(), dsc.data_ptr(), dfl.data_ptr(),
+                            torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize()
+            outs.append((drs.cpu().numpy(), dsc.cpu().numpy(), dfl.cpu().numpy()))
+        for a, b in zip(*outs):
+            np.testing.assert_array_equal(a, b)
+        assert (outs[0][2][[7, 8]] & 4).all() and (np.delete(outs[0][2], [7, 8]) & 4).sum() == 0
+        good = np.delete(np.arange(len(bad)), [7, 8])
+        np.testing.assert_array_equal(outs[0][0][good].astype(np.uint32), eng.resolve(q, False)[0][good])
+        # ordering off: natural order, no pairing, same rows
+        eng.set_option("scan_dp", 1)
+        eng.set_option("order", 0)
+        g2 = eng.resolve(q, False)
+        eng.set_option("order", 1)
+        g3 = eng.resolve(q, False)
+        for a, b in zip(g2, g3):
+            np.testing.assert_array_equal(a, b)
 
 
 def test_kernel_level_mirrors_honour_an_arbitrary_caller_mask(oracle):

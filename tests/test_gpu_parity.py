@@ -28,6 +28,8 @@ def engine(request):
     eng.set_option("svd_method", 1 if request.param == "hqr" else 0)
     if request.param == "hqr":
         eng.set_option("wg_min_quartets", 64)
+        # ... and every full-mode batch to the joint-histogram scan (scan_dp.hpp; by default from 32 768 quartets on)
+        eng.set_option("dp_min_quartets", 2)
     yield eng
     eng.close()
 

@@ -67,7 +67,7 @@ __global__ void tq_boot_perm_kernel(const int64_t *__restrict__ spans, const int
 __global__ void tq_boot_build_kernel(const uint8_t *__restrict__ seqarr, int64_t S0,
                                      const uint32_t *__restrict__ src_col, const uint32_t *__restrict__ site_locus,
                                      int64_t S, int64_t Sp, int64_t W, int32_t T, uint64_t seed,
-                                     uint8_t *__restrict__ rows, uint8_t *__restrict__ nib,
+                                     uint8_t *__restrict__ rows, uint8_t *__restrict__ nib, uint8_t *__restrict__ nib5,
                                      uint4 *__restrict__ planes, uint32_t *__restrict__ planes3,
                                      uint32_t *__restrict__ runbeg)
 {
@@ -76,7 +76,7 @@ __global__ void tq_boot_build_kernel(const uint8_t *__restrict__ seqarr, int64_t
     const int64_t t = gid / W, w = gid - t * W;
     uint8_t *dst = rows + t * Sp;
     uint32_t mm = 0, b0 = 0, b1 = 0, rb = 0;
-    uint32_t nw[4] = {0, 0, 0, 0};
+    uint32_t nw[4] = {0, 0, 0, 0}, n5[4] = {0, 0, 0, 0};
     for (int i = 0; i < 32; ++i) {
         const int64_t s = w * 32 + i;
         uint8_t code = 0;
@@ -105,6 +105,7 @@ __global__ void tq_boot_build_kernel(const uint8_t *__restrict__ seqarr, int64_t
         }
         dst[row_offset(s)] = code;
         nw[i >> 3] |= (uint32_t)code << (8 * (i & 3) + 4 * ((i >> 2) & 1));
+        n5[i >> 3] |= (uint32_t)(missing ? 4 : code) << (8 * (i & 3) + 4 * ((i >> 2) & 1));
         mm |= (uint32_t)missing << i;
         b0 |= (uint32_t)(code & 1) << i;
         b1 |= (uint32_t)((code >> 1) & 1) << i;
@@ -112,6 +113,7 @@ __global__ void tq_boot_build_kernel(const uint8_t *__restrict__ seqarr, int64_t
     planes[t * W + w] = make_uint4(mm, b0, b1, rb);
     store_planes3(planes3, runbeg, t, W, w, mm, b0, b1, rb);
     reinterpret_cast<uint4 *>(nib + t * (Sp / 2))[w] = make_uint4(nw[0], nw[1], nw[2], nw[3]);
+    reinterpret_cast<uint4 *>(nib5 + t * (Sp / 2))[w] = make_uint4(n5[0], n5[1], n5[2], n5[3]);
 }
 
 // replicate currently on the device -> the reference's tmparr (0..3, 78) / tmpmap layout

@@ -16,6 +16,7 @@ constexpr double DEGENERATE_REL_GAP = 1e-9;
 struct DevData {
     const uint8_t *rows;
     const uint8_t *nib;     // [T][Sp/2] two base codes per byte (see nib_offset)
+    const uint8_t *nib5;    // [T][Sp/2] the same with 4 for a missing cell (rows d1, d2 of the joint-histogram scan, scan_dp.hpp)
     const uint4 *planes;    // [T][W] {miss, p0, p1, runbeg}
     const uint32_t *planes3; // [T][W][3] {miss, p0, p1}: the compact copy the cooperative scan streams
     const uint32_t *runbeg;  // [W] run-begin bits (the same for every taxon)

@@ -17,7 +17,7 @@ __device__ __forceinline__ void store_planes3(uint32_t *planes3, uint32_t *runbe
 // ------------------------------------------------------------------------------------
 __global__ void tq_prepare_rows(const uint8_t *__restrict__ raw, const uint32_t *__restrict__ locus,
                                 int64_t S, int64_t Sp, int64_t W, int32_t T, uint8_t *__restrict__ rows,
-                                uint8_t *__restrict__ nib, uint4 *__restrict__ planes,
+                                uint8_t *__restrict__ nib, uint8_t *__restrict__ nib5, uint4 *__restrict__ planes,
                                 uint32_t *__restrict__ planes3, uint32_t *__restrict__ runbeg)
 {
     int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -26,7 +26,7 @@ __global__ void tq_prepare_rows(const uint8_t *__restrict__ raw, const uint32_t 
     const uint8_t *src = raw + t * S + w * 32;
     uint8_t *dst = rows + t * Sp;
     uint32_t mm = 0, b0 = 0, b1 = 0, rb = 0;
-    uint32_t nw[4] = {0, 0, 0, 0};                 // this word's 32 sites = 16 nibble bytes
+    uint32_t nw[4] = {0, 0, 0, 0}, n5[4] = {0, 0, 0, 0};   // this word's 32 sites = 16 nibble bytes (and with 4 = missing)
     for (int i = 0; i < 32; ++i) {
         int64_t s = w * 32 + i;
         uint8_t v = (s < S) ? src[i] : (uint8_t)0xFF;
@@ -34,6 +34,7 @@ __global__ void tq_prepare_rows(const uint8_t *__restrict__ raw, const uint32_t 
         uint8_t code = missing ? (uint8_t)0 : v;
         dst[row_offset(s)] = code;
         nw[i >> 3] |= (uint32_t)code << (8 * (i & 3) + 4 * ((i >> 2) & 1));
+        n5[i >> 3] |= (uint32_t)(missing ? 4 : code) << (8 * (i & 3) + 4 * ((i >> 2) & 1));
         mm |= (uint32_t)missing << i;
         b0 |= (uint32_t)(code & 1) << i;
         b1 |= (uint32_t)((code >> 1) & 1) << i;
@@ -45,6 +46,7 @@ __global__ void tq_prepare_rows(const uint8_t *__restrict__ raw, const uint32_t 
     planes[t * W + w] = make_uint4(mm, b0, b1, rb);
     store_planes3(planes3, runbeg, t, W, w, mm, b0, b1, rb);
     reinterpret_cast<uint4 *>(nib + t * (Sp / 2))[w] = make_uint4(nw[0], nw[1], nw[2], nw[3]);
+    reinterpret_cast<uint4 *>(nib5 + t * (Sp / 2))[w] = make_uint4(n5[0], n5[1], n5[2], n5[3]);
 }
 
 // ------------------------------------------------------------------------------------

@@ -53,6 +53,7 @@ namespace {
 #include "prepare.hpp"
 #include "scan.hpp"
 #include "scan_pb.hpp"
+#include "scan_dp.hpp"
 #include "jacobi.hpp"
 #include "hqr.hpp"
 #include "bootstrap.hpp"
@@ -74,6 +75,7 @@ struct tq_ctx {
     int64_t T = 0, S = 0, Sp = 0, W = 0;
     uint8_t *d_rows = nullptr;
     uint8_t *d_nib = nullptr;       // [T][Sp/2] nibble-packed copy of the rows (common.hpp: nib_offset)
+    uint8_t *d_nib5 = nullptr;      // [T][Sp/2] the same with 4 = missing (scan_dp.hpp)
     uint4 *d_planes = nullptr;      // [T][W] {miss, p0, p1, runbeg}
     uint32_t *d_planes3 = nullptr;  // [T][W][3] {miss, p0, p1}, then runbeg [W]
     bool have_data = false;
@@ -103,6 +105,10 @@ struct tq_ctx {
     void *d_sort_tmp = nullptr;
     size_t sort_tmp_bytes = 0;
     int order = 1;                  // 1 = process quartets in (a,b,c)-sorted order
+    uint2 *d_units = nullptr;       // cm_quartets + 2 entries: unit list of the joint-histogram scan (scan_dp.hpp), then its count
+    int scan_dp = 1;                // 1 = full-mode batches of >= dp_min_quartets go to tq_scan_dp_kernel (two quartets that share
+                                    // (a,b,c) per wave, one LDS atomic per site and pair)
+    int64_t dp_min_quartets = 32768;
     // singular-value stage scratch, sized for one chunk of `svd_chunk` quartets and re-used chunk after
     // chunk (so the bidiagonals / values of a chunk stay in the Infinity Cache between its three kernels):
     // de f64[3*chunk][32], sv f64[3*chunk][16], nsnps u32[chunk]
@@ -284,10 +290,12 @@ void free_data(tq_ctx *ctx)
 {
     if (ctx->d_rows) (void)hipFree(ctx->d_rows);
     if (ctx->d_nib) (void)hipFree(ctx->d_nib);
+    if (ctx->d_nib5) (void)hipFree(ctx->d_nib5);
     if (ctx->d_planes) (void)hipFree(ctx->d_planes);
     if (ctx->d_planes3) (void)hipFree(ctx->d_planes3);
     ctx->d_rows = nullptr;
     ctx->d_nib = nullptr;
+    ctx->d_nib5 = nullptr;
     ctx->d_planes = nullptr;
     ctx->d_planes3 = nullptr;
     ctx->have_data = false;
@@ -335,9 +343,11 @@ int ensure_cm(tq_ctx *ctx, int64_t quartets)
     if (ctx->d_cm) (void)hipFree(ctx->d_cm);
     if (ctx->d_sort) (void)hipFree(ctx->d_sort);
     if (ctx->d_sort_tmp) (void)hipFree(ctx->d_sort_tmp);
+    if (ctx->d_units) (void)hipFree(ctx->d_units);
     ctx->d_cm = nullptr;
     ctx->d_sort = nullptr;
     ctx->d_sort_tmp = nullptr;
+    ctx->d_units = nullptr;
     ctx->cm_quartets = 0;
     ctx->scanned_Q = 0;
     TQ_HIP(ctx, hipMalloc((void **)&ctx->d_cm, (size_t)quartets * 1024));
@@ -345,7 +355,11 @@ int ensure_cm(tq_ctx *ctx, int64_t quartets)
     size_t tmp = 0;
     uint32_t *k = ctx->d_sort;
     TQ_HIP(ctx, hipcub::DeviceRadixSort::SortPairs(nullptr, tmp, k, k, k, k, (int)quartets));
+    size_t tmp2 = 0;
+    TQ_HIP(ctx, hipcub::DeviceScan::InclusiveSum(nullptr, tmp2, k, k, (int)quartets));
+    if (tmp2 > tmp) tmp = tmp2;
     TQ_HIP(ctx, hipMalloc(&ctx->d_sort_tmp, tmp ? tmp : 16));
+    TQ_HIP(ctx, hipMalloc((void **)&ctx->d_units, ((size_t)quartets + 2) * sizeof(uint2)));
     ctx->sort_tmp_bytes = tmp;
     ctx->cm_quartets = quartets;
     return TQ_OK;
@@ -418,11 +432,55 @@ int make_order(tq_ctx *ctx, const uint32_t *dq, int64_t n, bool input_sorted, hi
     return TQ_OK;
 }
 
+// Joint-histogram scan (scan_dp.hpp) for this batch?  Full mode, automatic kernel choice, the default workgroup shape,
+// keys that hold (a,b,c), and an order the pairing can rely on (sorted here, or sorted on arrival).
+bool use_dp(const tq_ctx *ctx, int64_t n, int subsample, bool input_sorted)
+{
+    const uint64_t T = (uint64_t)ctx->T;
+    return !subsample && ctx->scan_dp && ctx->scan_method < 0 && ctx->scan_wg == 4 && !ctx->count_invariant &&
+           !ctx->share_c && !ctx->scan_pair && ctx->waves_per_cu == 0 && (ctx->order || input_sorted) &&
+           n >= ctx->dp_min_quartets && n >= 2 && n <= 0x7FFFFFFF && T * T * T <= 0xFFFFFFFFull &&
+           T * (uint64_t)ctx->Sp < 0xFFFF0000ull;
+}
+
+// ordering + unit list of the joint-histogram scan: d_units[0..count) = (first quartet, second quartet or DP_NONE) in
+// (a,b,c)-sorted order, count in d_units[cm_quartets] (read by the kernel: nothing comes back to the host)
+int make_units(tq_ctx *ctx, const uint32_t *dq, int64_t n, bool input_sorted, hipStream_t stream)
+{
+    uint32_t *keys_in = ctx->d_sort, *idx_in = keys_in + ctx->cm_quartets;
+    uint32_t *keys_out = idx_in + ctx->cm_quartets, *idx_out = keys_out + ctx->cm_quartets;
+    const uint64_t T = (uint64_t)ctx->T;
+    const unsigned blocks = (unsigned)((n + 255) / 256);
+    hipLaunchKernelGGL(tq_key_kernel, dim3(blocks), dim3(256), 0, stream, dq, n, (uint32_t)ctx->T, 1, keys_in, idx_in);
+    TQ_HIP(ctx, hipGetLastError());
+    const uint32_t *keys = keys_in, *idx = idx_in;
+    uint32_t *flags = keys_out;
+    if (!input_sorted) {
+        int bits = 1;
+        while (bits < 32 && (1ull << bits) < T * T * T) ++bits;
+        size_t tmp = ctx->sort_tmp_bytes;
+        TQ_HIP(ctx, hipcub::DeviceRadixSort::SortPairs(ctx->d_sort_tmp, tmp, keys_in, keys_out, idx_in, idx_out, (int)n,
+                                                       0, bits, stream));
+        keys = keys_out;
+        idx = idx_out;
+        flags = keys_in;
+    }
+    hipLaunchKernelGGL(tq_dp_flag_kernel, dim3(blocks), dim3(256), 0, stream, keys, idx, dq, n, (uint32_t)ctx->T, flags);
+    TQ_HIP(ctx, hipGetLastError());
+    size_t tmp = ctx->sort_tmp_bytes;
+    TQ_HIP(ctx, hipcub::DeviceScan::InclusiveSum(ctx->d_sort_tmp, tmp, flags, flags, (int)n, stream));
+    hipLaunchKernelGGL(tq_dp_units_kernel, dim3(blocks), dim3(256), 0, stream, keys, idx, (const uint32_t *)flags, n,
+                       ctx->d_units, reinterpret_cast<uint32_t *>(ctx->d_units + ctx->cm_quartets));
+    TQ_HIP(ctx, hipGetLastError());
+    return TQ_OK;
+}
+
 DevData dev_data(const tq_ctx *ctx)
 {
     DevData d;
     d.rows = ctx->d_rows;
     d.nib = ctx->d_nib;
+    d.nib5 = ctx->d_nib5;
     d.planes = ctx->d_planes;
     d.planes3 = ctx->d_planes3;
     d.runbeg = ctx->d_planes3 + (size_t)ctx->T * (size_t)ctx->plane_cap_W * 3;
@@ -540,6 +598,19 @@ int launch_scan_wg2(tq_ctx *ctx, const uint32_t *dq, const uint32_t *order, int6
     if (grid < 1) grid = 1;
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NW * WAVE), 0, stream, dev_data(ctx), dq, order, Q, ctx->d_cm,
                        xcd_chunk);
+    TQ_HIP(ctx, hipGetLastError());
+    return TQ_OK;
+}
+
+// joint-histogram scan over the unit list make_units left: at least ceil(Q / 2) units, at most Q -- the grid covers the
+// least (rounded to the 8 XCDs) and a workgroup whose id + grid is still a block takes that one as well
+int launch_scan_dp(tq_ctx *ctx, const uint32_t *dq, int64_t Q, hipStream_t stream)
+{
+    const int64_t least = ((Q + 1) / 2 + DP_NW - 1) / DP_NW;
+    const int64_t grid = (least + 7) / 8 * 8;
+    hipLaunchKernelGGL(tq_scan_dp_kernel<DP_NW>, dim3((unsigned)grid), dim3(DP_NW * WAVE), 0, stream, dev_data(ctx), dq,
+                       (const uint2 *)ctx->d_units, reinterpret_cast<const uint32_t *>(ctx->d_units + ctx->cm_quartets),
+                       ctx->d_cm);
     TQ_HIP(ctx, hipGetLastError());
     return TQ_OK;
 }
@@ -700,11 +771,18 @@ int stage_scan(tq_ctx *ctx, const uint32_t *dq, int64_t n, int subsample, bool i
     ctx->scanned_Q = 0;
     if ((rc = mark(ctx, TAG_ORIGIN, stream))) return rc;
     if (ctx->phases & 1) {
-        const uint32_t *order = nullptr;
-        rc = make_order(ctx, dq, n, input_sorted, stream, &order);
-        if (rc) return rc;
-        if ((rc = mark(ctx, TAG_ORDER, stream))) return rc;
-        rc = launch_scan_n(ctx, dq, order, n, subsample, stream);
+        if (use_dp(ctx, n, subsample, input_sorted)) {
+            rc = make_units(ctx, dq, n, input_sorted, stream);
+            if (rc) return rc;
+            if ((rc = mark(ctx, TAG_ORDER, stream))) return rc;
+            rc = launch_scan_dp(ctx, dq, n, stream);
+        } else {
+            const uint32_t *order = nullptr;
+            rc = make_order(ctx, dq, n, input_sorted, stream, &order);
+            if (rc) return rc;
+            if ((rc = mark(ctx, TAG_ORDER, stream))) return rc;
+            rc = launch_scan_n(ctx, dq, order, n, subsample, stream);
+        }
         if (rc) return rc;
         if ((rc = mark(ctx, TAG_SCAN, stream))) return rc;
     }
@@ -1065,6 +1143,7 @@ void tq_destroy(tq_ctx *ctx)
     if (ctx->d_cm) (void)hipFree(ctx->d_cm);
     if (ctx->d_sort) (void)hipFree(ctx->d_sort);
     if (ctx->d_sort_tmp) (void)hipFree(ctx->d_sort_tmp);
+    if (ctx->d_units) (void)hipFree(ctx->d_units);
     if (ctx->d_de) (void)hipFree(ctx->d_de);
     if (ctx->d_sv) (void)hipFree(ctx->d_sv);
     if (ctx->d_nsnps) (void)hipFree(ctx->d_nsnps);
@@ -1140,6 +1219,7 @@ int tq_set_data(tq_ctx *ctx, const uint8_t *tmparr, int64_t T, int64_t S, const 
     // the two upload temporaries here)
     hipError_t e = hipMalloc((void **)&ctx->d_rows, (size_t)(T * Sp));
     if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_nib, (size_t)(T * Sp / 2));
+    if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_nib5, (size_t)(T * Sp / 2));
     if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_planes, (size_t)(T * W) * sizeof(uint4));
     if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_planes3, (size_t)(T * W * 3 + W) * sizeof(uint32_t));
     ctx->plane_cap_W = W;
@@ -1157,7 +1237,7 @@ int tq_set_data(tq_ctx *ctx, const uint8_t *tmparr, int64_t T, int64_t S, const 
     if (e == hipSuccess) {
         const int64_t n = T * W;
         hipLaunchKernelGGL(tq_prepare_rows, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, d_raw, d_loc, S, Sp,
-                           W, (int32_t)T, ctx->d_rows, ctx->d_nib, ctx->d_planes,
+                           W, (int32_t)T, ctx->d_rows, ctx->d_nib, ctx->d_nib5, ctx->d_planes,
                            ctx->d_planes3,
                            ctx->d_planes3 + (size_t)T * (size_t)W * 3);
         e = hipGetLastError();
@@ -1445,6 +1525,16 @@ int tq_set_option(tq_ctx *ctx, const char *name, int64_t value)
         ctx->scan_pair = value != 0;
         return TQ_OK;
     }
+    if (!strcmp(name, "scan_dp")) {
+        if (value != 0 && value != 1) return fail(ctx, TQ_ERR_INVALID_ARG, "scan_dp must be 0 or 1");
+        ctx->scan_dp = (int)value;
+        return TQ_OK;
+    }
+    if (!strcmp(name, "dp_min_quartets")) {
+        if (value < 0) return fail(ctx, TQ_ERR_INVALID_ARG, "dp_min_quartets must be >= 0");
+        ctx->dp_min_quartets = value ? value : 32768;
+        return TQ_OK;
+    }
     if (!strcmp(name, "wg_min_quartets")) {
         if (value < 0) return fail(ctx, TQ_ERR_INVALID_ARG, "wg_min_quartets must be >= 0");
         ctx->wg_min_quartets = value ? value : 2048;
@@ -1615,6 +1705,7 @@ int tq_bootstrap_async(tq_ctx *ctx, const int64_t *lidxs, int64_t n, uint64_t se
         const int64_t capSp = (int64_t)align_up((size_t)(Sp + Sp / 8), TILE);   // head-room: replicate lengths vary
         TQ_HIP(ctx, hipMalloc((void **)&ctx->d_rows, (size_t)(T * capSp)));
         TQ_HIP(ctx, hipMalloc((void **)&ctx->d_nib, (size_t)(T * capSp / 2)));
+        TQ_HIP(ctx, hipMalloc((void **)&ctx->d_nib5, (size_t)(T * capSp / 2)));
         TQ_HIP(ctx, hipMalloc((void **)&ctx->d_planes, (size_t)(T * (capSp / 32)) * sizeof(uint4)));
         TQ_HIP(ctx, hipMalloc((void **)&ctx->d_planes3, (size_t)(T * (capSp / 32) * 3 + capSp / 32) * sizeof(uint32_t)));
         ctx->plane_cap_W = capSp / 32;
@@ -1638,7 +1729,7 @@ int tq_bootstrap_async(tq_ctx *ctx, const int64_t *lidxs, int64_t n, uint64_t se
                        ctx->d_lidxs, offsets, n, ctx->nloci, seed_shuffle, src_col, site_locus);
     const int64_t nw = T * W;
     hipLaunchKernelGGL(tq_boot_build_kernel, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, stream, ctx->d_seqarr,
-                       ctx->src_S0, src_col, site_locus, S, Sp, W, (int32_t)T, seed_ambig, ctx->d_rows, ctx->d_nib,
+                       ctx->src_S0, src_col, site_locus, S, Sp, W, (int32_t)T, seed_ambig, ctx->d_rows, ctx->d_nib, ctx->d_nib5,
                        ctx->d_planes, ctx->d_planes3, ctx->d_planes3 + (size_t)T * (size_t)ctx->plane_cap_W * 3);
     TQ_HIP(ctx, hipGetLastError());
     ctx->T = T;

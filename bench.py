@@ -216,7 +216,17 @@ def library_path() -> str:
     return p
 
 
-def kernel_rooflines(kms: dict, calls: int, Q: int, S: int, sub: bool, cfg: str):
+def dp_unit_count(quartets: np.ndarray, T: int) -> dict:
+    """Units (pairs of quartets that share their first three taxa + quartets on their own) the joint-histogram scan
+    (scan_dp.hpp, full mode) makes of a batch: inside a run of equal (a,b,c) of the sorted order neighbours are paired."""
+    q = np.asarray(quartets).reshape(-1, 4).astype(np.int64)
+    key = (q[:, 0] * T + q[:, 1]) * T + q[:, 2]
+    _, cnt = np.unique(key, return_counts=True)
+    pairs, singles = int((cnt // 2).sum()), int((cnt % 2).sum())
+    return {"pairs": pairs, "singles": singles, "units": pairs + singles}
+
+
+def kernel_rooflines(kms: dict, calls: int, Q: int, S: int, sub: bool, cfg: str, dp: dict | None = None):
     """roofline.kernels[]: per kernel the measured ms per pass (HIP events of THIS run) and the fraction
     (<= 1) of the roof that binds it, from a stated model of the work it has to do:
       scan    bytes it has to pull through the L2 -> CU path (4.4 KiB per quartet and 2048-site step: 3.5 KiB
@@ -235,7 +245,27 @@ def kernel_rooflines(kms: dict, calls: int, Q: int, S: int, sub: bool, cfg: str)
     if per.get("order", 0) > 0:
         out.append(dict(name="ordering (tq_key_kernel + radix sort)", ms=per["order"], bound="latency (~20 small launches)",
                         frac=None))
-    if per.get("scan", 0) > 0:
+    if per.get("scan", 0) > 0 and dp:
+        # full mode, joint-histogram scan (scan_dp.hpp): a wave scans a UNIT -- two quartets that share (a,b,c), or one --
+        # with one LDS atomic per site slot: per unit and 2048-site step 32 ds_add_u32 (5.1 LDS-array cycles each at 49 %
+        # lane occupancy, the birthday bound of ~16 random bins per 32 banks twice; counters of round 4,
+        # profiles/r04_scan/README.md section 8), 3 image reads ds_read_b128 (4), a quarter of the image stores; 6 vector
+        # loads for the unit's own rows c, d1, d2 (codes + plane records) + 4 per workgroup of 4 for the shared rows a, b
+        units = dp["units"] * (Q / max(1, dp["quartets"]))
+        loads = units * steps * (6 + 4 / 4)
+        ta_ms = loads * TA_CYCLES_PER_LOAD / 256 / 2.4e9 * 1e3
+        lds_cycles = 12 + 10.25 + 32 * 5.1
+        lds_ms = units * steps * lds_cycles / 256 / 2.4e9 * 1e3
+        out.append(dict(name="tq_scan_dp_kernel", ms=per["scan"],
+                        bound="co-bound: LDS instruction path (lds_path_frac), VALU issue; pmc shares in profiles/r04_scan/README.md section 8",
+                        achieved=loads / (per["scan"] / 1e3) / 1e9, peak=256 * 2.4 / TA_CYCLES_PER_LOAD,
+                        unit="G vector-load wave-instructions/s", frac=ta_ms / per["scan"],
+                        lds_path_frac=lds_ms / per["scan"], lds_path_cycles_per_wave_step=lds_cycles,
+                        units=dict(dp, quartets_per_wave_step=dp["quartets"] / max(1, dp["units"])),
+                        model=f"{dp['pairs']} pairs + {dp['singles']} single quartets of {dp['quartets']} = {dp['units']} units; 7 vector "
+                              f"loads per unit and 2048-site step x {TA_CYCLES_PER_LOAD} cycles = {ta_ms:.2f} ms; LDS instruction path "
+                              f"{lds_cycles:.0f} cycles per unit-step = {lds_ms:.2f} ms"))
+    elif per.get("scan", 0) > 0:
         # vector load instructions a CU has to issue: per wave and 2048-site step 4 for the wave's own rows c, d (2 x 16 B
         # nibble codes, 2 x 12 B plane records) + 4 per workgroup of 4 waves for the shared rows a, b; each costs the CU's
         # texture-address path ~18 cycles whatever its width (tools/probe_ta.hip, profiles/r03_scan/probe_ta.txt)
@@ -280,7 +310,7 @@ def kernel_rooflines(kms: dict, calls: int, Q: int, S: int, sub: bool, cfg: str)
         ach = by / (per["score"] / 1e3) / 1e9
         out.append(dict(name="tq_score_kernel", ms=per["score"], bound="hbm", achieved=ach, peak=HBM_PEAK_GBS,
                         unit="GB/s", frac=ach / HBM_PEAK_GBS, model="437 B per quartet read + written"))
-    pmc = REPO / "profiles" / "pmc_busy_latest.json"
+    pmc = REPO / "profiles" / ("pmc_busy_latest.json" if sub else "pmc_busy_full_latest.json")
     if pmc.exists():
         try:
             info = json.loads(pmc.read_text())
@@ -288,7 +318,7 @@ def kernel_rooflines(kms: dict, calls: int, Q: int, S: int, sub: bool, cfg: str)
                 for name, v in info.get("kernels", {}).items():
                     if name in k["name"]:
                         k["pmc"] = dict({x: v[x] for x in ("valu_busy", "lds_busy", "lds_conflict_share", "ta_busy") if x in v},
-                                        source="profiles/pmc_busy_latest.json: " + str(info.get("source")),
+                                        source=f"profiles/{pmc.name}: " + str(info.get("source")),
                                         commit=info.get("commit"))
         except Exception:
             pass
@@ -803,7 +833,13 @@ def main(argv=None):
                     + (f" in one batch cut over {world} GPUs (strong scaling)" if multi and not weak else "")
                     + (f" = {Q // world} per GPU (weak scaling: the N = 1 workload on every GPU)" if weak else "")
                     + f", subsample_snps={sub}, results delivered to host arrays inside the step")
-        kernels = kernel_rooflines(kms_serial, launches_serial, q_rank, S, sub, cfg)
+        dp = None
+        opts = dict(kv.split("=") for kv in args.opt)
+        if (not sub and q_rank >= int(opts.get("dp_min_quartets", 0) or 32768) and T ** 3 < 2 ** 32 and not multi
+                and int(opts.get("scan_dp", 1)) and int(opts.get("scan_method", -1)) < 0 and int(opts.get("order", 1))
+                and (args.order != 0) and locals().get("quartets_h") is not None):
+            dp = dict(dp_unit_count(np.array(locals()["quartets_h"]), T), quartets=Q)
+        kernels = kernel_rooflines(kms_serial, launches_serial, q_rank, S, sub, cfg, dp)
         line = {
             "metric": "resolved quartets/sec (whole node)", "value": value, "unit": "quartets/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
@@ -871,7 +907,7 @@ def roofline_block(achieved, dominant_ms, bytes_per_launch, traffic, traffic_src
            "note": ("algorithmic bytes (SURVEY 8d: 4*S+48 per quartet) over the dominant kernel's time; the "
                     "genotype matrix is L2 / Infinity-Cache resident, so this exceeds the HBM peak and is NOT an "
                     "efficiency figure -- binding / binding_frac / svd_f64_frac / kernels[].frac are"),
-           "kernel": "tq_scan_wg_kernel", "kernel_ms": dominant_ms,
+           "kernel": (scan or {}).get("name", "tq_scan_wg_kernel"), "kernel_ms": dominant_ms,
            "algorithmic_bytes_per_launch": bytes_per_launch,
            "traffic": traffic, "traffic_source": traffic_src,
            "traffic_over_algorithmic": (traffic / bytes_per_launch if traffic else None),

@@ -25,10 +25,32 @@
 // v_add_co (count mask -> lane mask) + v_bfe (the field IS the address) + ds_add_u32.
 #pragma once
 
+#ifndef TQ_DP_PRIO
+#define TQ_DP_PRIO 2
+#endif
+#define TQ_DP_STR_(x) #x
+#define TQ_DP_STR(x) TQ_DP_STR_(x)
+#if TQ_DP_PRIO
+#define TQ_DP_PRIO_ON "s_setprio " TQ_DP_STR(TQ_DP_PRIO)
+#define TQ_DP_PRIO_OFF "s_setprio 0"
+#else
+#define TQ_DP_PRIO_ON ""
+#define TQ_DP_PRIO_OFF ""
+#endif
 constexpr int DP_NW = 4;                    // waves (= pairs) per workgroup
 constexpr int DP_ROWS = 25;                 // values of E
 constexpr int DP_HIST_DW = DP_ROWS * 64;    // 1600 counters per wave (6400 bytes)
+#ifndef TQ_DP_SWZ
+#define TQ_DP_SWZ 0
+#endif
+// what the bank swizzle XORs into the counter index (a<<4|b<<2|c) of row E = 5 d1' + d2'
+__host__ __device__ constexpr int dp_swz(int e)
+{
+    return TQ_DP_SWZ >= 2 ? ((e / 5) ^ (((e / 5 + e % 5) << 2) & 63)) : (TQ_DP_SWZ == 1 ? e / 5 : 0);
+}
 constexpr uint32_t DP_NONE = 0xFFFFFFFFu;   // units[].y of a quartet without a partner
+constexpr int DP_SLOTS = 192;               // uint4 slots of the shared image (scan.hpp's without the run-begin words): with
+                                            // 208 a workgroup needs 32 256 bytes of LDS and a CU holds four, with 192 five
 
 // ---- building the unit list from the sorted order ---------------------------------------------------------------
 // keys[] = sort keys (a*T+b)*T+c in ascending order, idx[] = the quartets' original indices in that order.  Inside a
@@ -96,7 +118,7 @@ tq_scan_dp_kernel(DevData d, const uint32_t *__restrict__ quartets, const uint2 
                   const uint32_t *__restrict__ nunits_dev, uint32_t *__restrict__ cm)
 {
     static_assert(NW >= 2 && NW <= 8, "waves per workgroup");
-    __shared__ uint4 shared_ab[2][SHARED_SLOTS];
+    __shared__ uint4 shared_ab[2][DP_SLOTS];
     __shared__ __attribute__((aligned(256))) uint32_t hist_all[NW][DP_HIST_DW];
     const int tid = threadIdx.x;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -235,12 +257,18 @@ tq_scan_dp_kernel(DevData d, const uint32_t *__restrict__ quartets, const uint2 
                 const uint32_t m3c = 0x3C3C3C3Cu;
                 uint32_t W[16];
                 auto build8 = [&](int j, uint32_t cw, uint32_t x, uint32_t y, uint32_t abl, uint32_t abh) {
-                    const uint32_t hb03 = ((cw << 2) & m3c) | abl;             // sites 8j .. 8j+3
-                    const uint32_t hb47 = ((cw >> 2) & m3c) | abh;             // sites 8j+4 .. 8j+7
+                    uint32_t hb03 = ((cw << 2) & m3c) | abl;                   // sites 8j .. 8j+3
+                    uint32_t hb47 = ((cw >> 2) & m3c) | abh;                   // sites 8j+4 .. 8j+7
                     const uint32_t yy = (y & keep2) | force_code;              // (4 in every nibble for a unit of one quartet)
                     const uint32_t s = x + yy;                                 // d1' + d2' per nibble (<= 8)
-                    const uint32_t e03 = ((x << 2) & m3c) + (s & m0f) + B4;
-                    const uint32_t e47 = ((x >> 2) & m3c) + ((s >> 4) & m0f) + B4;
+                    const uint32_t t03 = (x << 2) & m3c, t47 = (x >> 2) & m3c;  // 4 d1' per byte
+                    const uint32_t u03 = s & m0f, u47 = (s >> 4) & m0f;        // d1' + d2' per byte
+                    const uint32_t e03 = t03 + u03 + B4;
+                    const uint32_t e47 = t47 + u47 + B4;
+                    // bank swizzle: the counter's bank is (a,b,c) mod 32 as it stands, and (a,b,c) is the most skewed part of
+                    // the pattern; d1' (and d1' + d2') are XOR-ed into it -- dp_swz() below is the same function of the row E
+                    if (TQ_DP_SWZ >= 1) { hb03 ^= t03; hb47 ^= t47; }
+                    if (TQ_DP_SWZ >= 2) { hb03 ^= u03 << 4; hb47 ^= u47 << 4; }
                     W[4 * j + 0] = __builtin_amdgcn_perm(e03, hb03, 0x05010400u);   // sites 8j, 8j+1
                     W[4 * j + 1] = __builtin_amdgcn_perm(e03, hb03, 0x07030602u);   // sites 8j+2, 8j+3
                     W[4 * j + 2] = __builtin_amdgcn_perm(e47, hb47, 0x05010400u);
@@ -258,7 +286,7 @@ tq_scan_dp_kernel(DevData d, const uint32_t *__restrict__ quartets, const uint2 
                 {
                     uint32_t c = C, a, one = 1u;
                     uint64_t save;
-                    asm volatile("s_mov_b64 %0, exec" : "=s"(save));
+                    asm volatile("s_mov_b64 %0, exec\n\t" TQ_DP_PRIO_ON : "=s"(save));
 #define TQ_DP_SLOT(J, K)                                                                                        \
                     asm volatile("v_add_co_u32_e32 %[c], vcc, %[c], %[c]\n\t"                                     \
                                  "v_bfe_u32 %[a], %[p], " #K "*16, 16\n\t"                                         \
@@ -274,6 +302,7 @@ tq_scan_dp_kernel(DevData d, const uint32_t *__restrict__ quartets, const uint2 
                     TQ_DP_SLOT2(3) TQ_DP_SLOT2(2) TQ_DP_SLOT2(1) TQ_DP_SLOT2(0)
 #undef TQ_DP_SLOT2
 #undef TQ_DP_SLOT
+                    asm volatile(TQ_DP_PRIO_OFF ::: "memory");
                 }
 #else
                 {
@@ -317,8 +346,8 @@ tq_scan_dp_kernel(DevData d, const uint32_t *__restrict__ quartets, const uint2 
             uint32_t v[DP_ROWS];
 #pragma unroll
             for (int e = 0; e < DP_ROWS; ++e) {
-                v[e] = hist[e * 64 + lane];
-                hist[e * 64 + lane] = 0;
+                v[e] = hist[e * 64 + (lane ^ dp_swz(e))];
+                hist[e * 64 + (lane ^ dp_swz(e))] = 0;
             }
             uint32_t c1[4], c2[4];
 #pragma unroll

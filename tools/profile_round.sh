@@ -19,6 +19,19 @@ python3 tools/pmc_traffic.py $O/pmc_f $O/pmc_w --out $O/traffic_c3_sub.json --co
 python3 tools/pmc_busy.py $O/sq1 $O/sq2 $O/sq3 --out $O/pmc_busy.json --source "rocprofv3 --pmc passes of python3 bench.py --no-cpu (c3 sub)" --commit $(cat .build_commit)
 cp $O/pmc_busy.json profiles/pmc_busy_latest.json; cp $O/traffic_c3_sub.json profiles/traffic_c3_sub.json   # what bench.py quotes
 find $O/stats -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $O/kernel_stats.csv
+# the same for full mode (subsample_snps=False, the reference's default: tq_scan_dp_kernel)
+$P --kernel-trace --stats -d $O/stats_full --output-format csv -- python3 bench.py --full --no-other-mode --no-cpu --steps 8 --warmup 2 > $O/bench_full_under_rocprof.json 2> $O/stats_full.err
+find $O/stats_full -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $O/kernel_stats_full.csv
+$P --kernel-trace --pmc FETCH_SIZE -d $O/pmc_ff --output-format csv -- python3 bench.py --full --no-other-mode --no-cpu --steps 4 --warmup 1 > /dev/null 2> $O/pmc_ff.err
+$P --kernel-trace --pmc WRITE_SIZE -d $O/pmc_fw --output-format csv -- python3 bench.py --full --no-other-mode --no-cpu --steps 4 --warmup 1 > /dev/null 2> $O/pmc_fw.err
+$P --kernel-trace --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_INSTS_SALU SQ_WAIT_INST_LDS SQ_WAIT_ANY SQ_INSTS_VMEM -d $O/sqf1 --output-format csv -- python3 bench.py --full --no-other-mode --no-cpu --steps 3 --warmup 1 > /dev/null 2> $O/sqf1.err
+$P --kernel-trace --pmc SQ_INSTS_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS -d $O/sqf2 --output-format csv -- python3 bench.py --full --no-other-mode --no-cpu --steps 3 --warmup 1 > /dev/null 2> $O/sqf2.err
+$P --kernel-trace --pmc TA_TA_BUSY_sum TA_FLAT_READ_WAVEFRONTS_sum -d $O/sqf3 --output-format csv -- python3 bench.py --full --no-other-mode --no-cpu --steps 3 --warmup 1 > /dev/null 2> $O/sqf3.err || true
+python3 tools/pmc_traffic.py $O/pmc_ff $O/pmc_fw --out $O/traffic_c3_full.json --config "c3 full, 1e6 quartets per launch" --commit $(cat .build_commit) --copy-to $O/csv_full
+python3 tools/pmc_busy.py $O/sqf1 $O/sqf2 $O/sqf3 --out $O/pmc_busy_full.json --source "rocprofv3 --pmc passes of python3 bench.py --full --no-cpu (c3 full)" --commit $(cat .build_commit)
+cp $O/pmc_busy_full.json profiles/pmc_busy_full_latest.json; cp $O/traffic_c3_full.json profiles/traffic_c3_full.json
+rm -rf $O/stats_full $O/pmc_ff $O/pmc_fw $O/sqf1 $O/sqf2 $O/sqf3
+echo full-mode passes done
 rm -rf $O/stats $O/pmc_f $O/pmc_w $O/sq1 $O/sq2 $O/sq3
 python3 bench.py --steps 10 --warmup 2 > $O/bench.json 2> $O/bench.err
 echo bench done

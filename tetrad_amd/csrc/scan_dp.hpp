@@ -69,11 +69,16 @@ __device__ __forceinline__ int dp_role(const uint32_t *__restrict__ keys, const 
                                        const uint32_t *__restrict__ quartets, int64_t n, uint32_t T, int64_t i)
 {
     const uint32_t k = keys[i];
-    // first element of the run: lower bound of k in keys[0..i]
-    int64_t lo = 0, hi = i;
-    while (lo < hi) {
-        const int64_t mid = (lo + hi) >> 1;
-        if (keys[mid] < k) lo = mid + 1; else hi = mid;
+    // first element of the run: a few steps back (runs are short in a random sample), else the lower bound of k in keys[0..i]
+    int64_t lo = i;
+    for (int step = 0; step < 8 && lo > 0 && keys[lo - 1] == k; ++step) --lo;
+    if (lo > 0 && keys[lo - 1] == k) {
+        int64_t hi = lo;
+        lo = 0;
+        while (lo < hi) {
+            const int64_t mid = (lo + hi) >> 1;
+            if (keys[mid] < k) lo = mid + 1; else hi = mid;
+        }
     }
     const bool odd = ((i - lo) & 1) != 0;
     const bool ok = dp_valid(quartets, idx[i], T);

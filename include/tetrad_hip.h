@@ -223,7 +223,11 @@ int tq_timing_read_kernels(tq_ctx *ctx, double *ms, int n_ms, int64_t *calls);
  * default 60), bdsqr_stats (1: count rotation steps / issued lane-slots, read with tq_debug_fetch which = 3), phases
  * (timing diagnostics).  scan_method 2..5 and phases 1 / 2 are timing diagnostics whose rows are wrong: every row of a
  * call made under them carries TQ_FLAG_INVALID_DIAGNOSTIC and a call without a flags array fails.  scan_method 6 = the
- * bank-private counter kernel (scan_pb.hpp; an A/B form, slower).  batch is clamped to 2^31 - 1.          */
+ * bank-private counter kernel (scan_pb.hpp; an A/B form, slower).  batch is clamped to 2^31 - 1.
+ * scan_dp (1, default: full-mode batches -- subsample = 0 -- of at least dp_min_quartets go to the joint-histogram scan,
+ * scan_dp.hpp: two quartets that share their first three taxa per wavefront, one LDS atomic per site and pair; the same rows,
+ * bit for bit; 0: always one quartet per wavefront), dp_min_quartets (default 32 768; smaller batches are not sorted and hold
+ * few pairs).                                                                                                        */
 int tq_set_option(tq_ctx *ctx, const char *name, int64_t value);
 
 /* Test hook: copy the scratch of the last resolve call to the host.  which = 0: count slab

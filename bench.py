@@ -226,7 +226,7 @@ def dp_unit_count(quartets: np.ndarray, T: int) -> dict:
     return {"pairs": pairs, "singles": singles, "units": pairs + singles}
 
 
-def kernel_rooflines(kms: dict, calls: int, Q: int, S: int, sub: bool, cfg: str, dp: dict | None = None):
+def kernel_rooflines(kms: dict, calls: int, Q: int, S: int, sub: bool, cfg: str, dp: dict | None = None, f4: bool = False):
     """roofline.kernels[]: per kernel the measured ms per pass (HIP events of THIS run) and the fraction
     (<= 1) of the roof that binds it, from a stated model of the work it has to do:
       scan    bytes it has to pull through the L2 -> CU path (4.4 KiB per quartet and 2048-site step: 3.5 KiB
@@ -265,6 +265,26 @@ def kernel_rooflines(kms: dict, calls: int, Q: int, S: int, sub: bool, cfg: str,
                         model=f"{dp['pairs']} pairs + {dp['singles']} single quartets of {dp['quartets']} = {dp['units']} units; 7 vector "
                               f"loads per unit and 2048-site step x {TA_CYCLES_PER_LOAD} cycles = {ta_ms:.2f} ms; LDS instruction path "
                               f"{lds_cycles:.0f} cycles per unit-step = {lds_ms:.2f} ms"))
+    elif per.get("scan", 0) > 0 and f4:
+        # the plane-record scan (scan_f4.hpp: SURVEY 8 row f4 as written, the default of subsample mode): per wave and 2048-site step
+        # 2 vector loads for the wave's own rows c, d (one 12-byte plane record each) + 4 per workgroup of 4 waves for the shared
+        # rows a, b; LDS instruction path: image reads ds_read_b128 (4) + ds_read_b32 (2); image stores, a quarter of 8 x
+        # ds_write_addtid_b32 (2) + b128 (13) + b32 (4); walk trips (8.2 in subsample mode on c3, 19 in full mode) x (ds_read_u8
+        # 2 + ds_add_u32 5.8 array cycles); no park.  15 vector instructions per walk trip (6 in tq_scan_wg_kernel).
+        loads = Q * steps * (2 + 4 / 4)
+        ta_ms = loads * TA_CYCLES_PER_LOAD / 256 / 2.4e9 * 1e3
+        trips = 8.2 if sub else 19.0
+        lds_cycles = 6 + (16 + 17) / 4 + trips * (2 + 5.8)
+        lds_ms = Q * steps * lds_cycles / 256 / 2.4e9 * 1e3
+        out.append(dict(name="tq_scan_f4_kernel", ms=per["scan"],
+                        bound="co-bound: LDS instruction path (lds_path_frac), VALU issue (2 wave-instructions per cycle and CU), "
+                              "texture-address issue (frac); pmc shares below",
+                        achieved=loads / (per["scan"] / 1e3) / 1e9, peak=256 * 2.4 / TA_CYCLES_PER_LOAD,
+                        unit="G vector-load wave-instructions/s", frac=ta_ms / per["scan"],
+                        lds_path_frac=lds_ms / per["scan"], lds_path_cycles_per_wave_step=lds_cycles,
+                        model=f"3 vector loads per quartet and 2048-site step x {TA_CYCLES_PER_LOAD} cycles of a CU's texture-address "
+                              f"path each = {ta_ms:.2f} ms at 2.4 GHz; LDS instruction path {lds_cycles:.0f} cycles per wave-step = "
+                              f"{lds_ms:.2f} ms; 141 vector instructions per wave-step (profiles/r04_scan/README.md section 9)"))
     elif per.get("scan", 0) > 0:
         # vector load instructions a CU has to issue: per wave and 2048-site step 4 for the wave's own rows c, d (2 x 16 B
         # nibble codes, 2 x 12 B plane records) + 4 per workgroup of 4 waves for the shared rows a, b; each costs the CU's
@@ -836,10 +856,15 @@ def main(argv=None):
         dp = None
         opts = dict(kv.split("=") for kv in args.opt)
         if (not sub and q_rank >= int(opts.get("dp_min_quartets", 0) or 32768) and T ** 3 < 2 ** 32 and not multi
-                and int(opts.get("scan_dp", 1)) and int(opts.get("scan_method", -1)) < 0 and int(opts.get("order", 1))
+                and int(opts.get("scan_dp", 1)) and int(opts.get("scan_f4", -1)) <= 0 and int(opts.get("scan_method", -1)) < 0
+                and int(opts.get("order", 1))
                 and (args.order != 0) and locals().get("quartets_h") is not None):
             dp = dict(dp_unit_count(np.array(locals()["quartets_h"]), T), quartets=Q)
-        kernels = kernel_rooflines(kms_serial, launches_serial, q_rank, S, sub, cfg, dp)
+        f4_opt = int(opts.get("scan_f4", -1))
+        plain = (int(opts.get("scan_method", -1)) < 0 and int(opts.get("park_t", 1)) and not int(opts.get("scan_pair", 0))
+                 and not int(opts.get("share_c", 0)) and int(opts.get("scan_wg", 0)) in (0, 4))
+        f4 = plain and (f4_opt == 1 or (f4_opt < 0 and sub)) and dp is None
+        kernels = kernel_rooflines(kms_serial, launches_serial, q_rank, S, sub, cfg, dp, f4)
         line = {
             "metric": "resolved quartets/sec (whole node)", "value": value, "unit": "quartets/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
@@ -982,14 +1007,14 @@ def bench_c5(args, eng, torch, dist, dev, world, rank):
                        "subsample_snps": sub, "sampler": args.sampler,
                        "parallelism": f"replicate-sequential RNG (run_inference.py:378-407), quartet-sharded x{world}"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "kernel": "tq_scan_wg_kernel", "kernel_ms": per_pass["scan"],
+                         "frac": achieved / HBM_PEAK_GBS, "kernel": "tq_scan_f4_kernel" if sub else "tq_scan_dp_kernel", "kernel_ms": per_pass["scan"],
                          "algorithmic_bytes_per_launch": bytes_per_launch, "traffic": None,
                          "traffic_source": "not measured in this run",
                          "all_kernels_ms_per_step": sum(per_pass.values()),
                          "kernels_note": ("event spans of the timed region; the singular-value chunks of a replicate run on two "
                                           "streams, so the bidiag / bdsqr / score spans overlap and over-state each kernel's own "
                                           "duration (the c3 line of the default run has them serialised)"),
-                         "kernels": kernel_rooflines(kms, launches, q_rank, S, sub, "c3")},
+                         "kernels": kernel_rooflines(kms, launches, q_rank, S, sub, "c3", None, bool(sub))},
             "host_draw_ms_per_replicate_mean": float(np.mean(stats["host_ms"])),
             "main_thread_wait_for_draws_ms_mean": float(np.mean(stats["wait_ms"])),
             "flags": stats["flags"], "rng_state_matches_reference_draw_order": rng_check,

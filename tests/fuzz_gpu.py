@@ -43,9 +43,9 @@ while time.time() < t_end:
             "svd_chunk": int(rng.choice([0, 0, 1, 100, 1024])), "svd_streams": int(rng.choice([0, 0, 1])),
             "share_c": int(rng.choice([0, 0, 1])), "park_t": int(rng.choice([1, 1, 0])), "scan_pair": int(rng.choice([0, 0, 1])),
             "scan_method": int(rng.choice([-1, -1, 0, 1, 6])), "bidiag_layout": int(rng.choice([1, 1, 0])), "wg_min_quartets": int(rng.choice([0, 64, 64])),
-            "scan_dp": int(rng.choice([1, 1, 0])), "dp_min_quartets": int(rng.choice([0, 2, 2, 500]))}
+            "scan_dp": int(rng.choice([1, 1, 0])), "scan_f4": int(rng.choice([-1, -1, 0, 1])), "dp_min_quartets": int(rng.choice([0, 2, 2, 500]))}
     if rng.random() < 0.35:              # the option set under which full-mode batches go to the joint-histogram scan (scan_dp.hpp)
-        opts.update(scan_wg=0, scan_method=-1, share_c=0, scan_pair=0, scan_dp=1, dp_min_quartets=2)
+        opts.update(scan_wg=0, scan_method=-1, share_c=0, scan_pair=0, scan_dp=1, scan_f4=-1, dp_min_quartets=2)
     for k, v in opts.items():
         eng.set_option(k, v)
     eng.set_data(tmparr, tmpmap)

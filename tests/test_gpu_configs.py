@@ -228,24 +228,24 @@ def test_kernel_level_mirrors(case):
 
 @pytest.mark.parametrize("cfg,nq", [("c3", 40_000), ("c2", 60_000)])
 def test_scan_kernel_variants_agree_on_sorted_batches(cfg, nq):
-    """Batches large enough to be sorted by (a,b,c) and scanned by the cooperative kernel with shared rows
-    (>= 32 768 quartets): every alternative form of the scan kernel -- lane-contiguous pattern park, two quartets per
-    wavefront, row c through LDS, 8-wave workgroups, EXEC-masked counting in subsample mode and the walk in full
-    mode, bank-private counters (scan_pb.hpp, the default of full mode) in subsample mode -- must give bitwise the rows
-    of the default form, in both modes."""
+    """Batches large enough to be sorted by (a,b,c) and scanned by the cooperative kernels with shared rows
+    (>= 32 768 quartets): every alternative form of the scan -- the nibble-code kernel of rounds 1-3 with its lane-contiguous
+    pattern park, two quartets per wavefront, row c through LDS, 8-wave workgroups, EXEC-masked counting in subsample mode and
+    the walk in full mode, bank-private counters (scan_pb.hpp), the plane-record scan in full mode, no joint histogram -- must
+    give bitwise the rows of the default forms (subsample: scan_f4.hpp, full: scan_dp.hpp), in both modes."""
     from tetrad_amd import synth
     from tetrad_amd.engine import QuartetEngine
     T, S, _ = synth.CONFIGS[cfg]
     tmparr, tmpmap = synth.simulate_tmparr(T, S, synth.CONFIG_SEEDS[cfg])
     q = synth.all_quartets(T)[:nq] if cfg == "c2" else synth.random_quartets(T, nq, seed=5)
-    defaults = {"park_t": 1, "scan_pair": 0, "share_c": 0, "scan_wg": 0, "scan_method": -1, "scan_dp": 1}
+    defaults = {"park_t": 1, "scan_pair": 0, "share_c": 0, "scan_wg": 0, "scan_method": -1, "scan_dp": 1, "scan_f4": -1}
     with QuartetEngine(0) as eng:
         eng.set_data(tmparr, tmpmap)
         for sub in (True, False):
             base = eng.resolve(q, sub)
             for opts in ({"park_t": 0}, {"scan_pair": 1}, {"scan_pair": 1, "scan_method": 1 - int(sub)}, {"share_c": 1},
                          {"scan_wg": 8}, {"scan_method": 1 - int(sub)}, {"scan_method": 6}, {"scan_method": int(sub)},
-                         {"scan_dp": 0}):
+                         {"scan_dp": 0}, {"scan_f4": 1}, {"scan_f4": 0}, {"scan_f4": 0, "scan_dp": 0}, {"scan_wg": 8, "scan_f4": 0}):
                 for k, v in opts.items():
                     eng.set_option(k, v)
                 got = eng.resolve(q, sub)
@@ -253,6 +253,30 @@ def test_scan_kernel_variants_agree_on_sorted_batches(cfg, nq):
                     eng.set_option(k, defaults[k])
                 for a, b in zip(base, got):
                     np.testing.assert_array_equal(a, b, err_msg=f"{opts} sub={sub}")
+
+
+@pytest.mark.parametrize("case", ["dense_T8_S400", "tree_T12_S2000", "sparse_T10_S257", "edge_T7_S130", "carry_T6_S2500",
+                                  "minrank_T14_S600"])
+def test_row_f4_kernel_on_golden_cases(case):
+    """SURVEY 8 row f4 as written -- the cooperative scan on ONE 12-byte plane record per taxon and 32-site lane-step, pattern
+    bits of counted sites pulled out of the plane words inside the walk (scan_f4.hpp, option scan_f4) -- against the
+    reference's count matrices and rows, both modes."""
+    from test_gpu_parity import check_against
+    from tetrad_amd.engine import QuartetEngine
+    g = dict(load_golden(case))
+    nq = len(g["quartets"])
+    if nq < 64:                                   # the cooperative kernels take batches of 64 quartets or more: repeat the case
+        reps = -(-64 // nq)
+        for k, v in list(g.items()):
+            if isinstance(v, np.ndarray) and v.ndim >= 1 and v.shape[0] == nq and k not in ("tmparr", "tmpmap"):
+                g[k] = np.concatenate([v] * reps, axis=0)
+    with QuartetEngine(0) as eng:
+        eng.set_option("scan_f4", 1)
+        eng.set_option("wg_min_quartets", 64)
+        eng.set_data(g["tmparr"], g["tmpmap"])
+        for mode in ("full", "sub"):
+            rstat, rscor, flags, dbg = eng.resolve(g["quartets"], mode == "sub", debug=True)
+            check_against(g, mode, rstat, rscor, flags, dbg)
 
 
 def test_joint_histogram_scan_on_messy_batches(oracle):

@@ -17,15 +17,24 @@ RTOL = 1e-6
 ATOL_REL_SMAX = 1e-12
 
 
-@pytest.fixture(scope="module", params=["hqr", "jacobi"])
+@pytest.fixture(scope="module", params=["hqr", "jacobi", "hqr-one-quartet-kernels"])
 def engine(request):
     """Every parity test runs against both device SVD paths: Householder + bidiagonal QR
     (default) and one-sided Jacobi -- and against both scan kernels: the "hqr" engine sends every batch of 64 quartets or
-    more to the cooperative workgroup kernel (the default threshold is 2 048: smaller calls are latency-bound and go to the
-    one-wave-per-quartet kernel), the "jacobi" engine keeps the default, so the small golden cases cover both."""
+    more to the cooperative workgroup kernels (the default threshold is 2 048: smaller calls are latency-bound and go to the
+    one-wave-per-quartet kernel) -- subsample mode to the plane-record scan (scan_f4.hpp), full mode to the joint-histogram scan
+    (scan_dp.hpp) -- the "jacobi" engine keeps the defaults, so the small golden cases cover the one-wave kernel, and the third
+    engine runs the cooperative kernel of rounds 1-3 in both modes."""
     from tetrad_amd.engine import QuartetEngine
     eng = QuartetEngine(0)
-    eng.set_option("svd_method", 1 if request.param == "hqr" else 0)
+    eng.set_option("svd_method", 0 if request.param == "jacobi" else 1)
+    if request.param == "hqr-one-quartet-kernels":
+        # the cooperative kernel on nibble codes + plane records (tq_scan_wg_kernel: the default of rounds 1-3 and still that of
+        # full-mode batches under 32 768 quartets) in both modes: no joint histogram, no plane-record-only scan
+        eng.set_option("svd_method", 1)
+        eng.set_option("wg_min_quartets", 64)
+        eng.set_option("scan_dp", 0)
+        eng.set_option("scan_f4", 0)
     if request.param == "hqr":
         eng.set_option("wg_min_quartets", 64)
         # ... and every full-mode batch to the joint-histogram scan (scan_dp.hpp; by default from 32 768 quartets on)

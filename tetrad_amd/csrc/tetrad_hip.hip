@@ -54,6 +54,7 @@ namespace {
 #include "scan.hpp"
 #include "scan_pb.hpp"
 #include "scan_dp.hpp"
+#include "scan_f4.hpp"
 #include "jacobi.hpp"
 #include "hqr.hpp"
 #include "bootstrap.hpp"
@@ -106,6 +107,8 @@ struct tq_ctx {
     size_t sort_tmp_bytes = 0;
     int order = 1;                  // 1 = process quartets in (a,b,c)-sorted order
     uint2 *d_units = nullptr;       // cm_quartets + 2 entries: unit list of the joint-histogram scan (scan_dp.hpp), then its count
+    int scan_f4 = -1;               // the cooperative scan on 12-byte plane records only (SURVEY 8 row f4 as written; scan_f4.hpp):
+                                    // -1 = in subsample mode (c3 scan 5.81 -> 5.58 ms), 1 = in both modes, 0 = never
     int scan_dp = 1;                // 1 = full-mode batches of >= dp_min_quartets go to tq_scan_dp_kernel (two quartets that share
                                     // (a,b,c) per wave, one LDS atomic per site and pair)
     int64_t dp_min_quartets = 32768;
@@ -437,7 +440,7 @@ int make_order(tq_ctx *ctx, const uint32_t *dq, int64_t n, bool input_sorted, hi
 bool use_dp(const tq_ctx *ctx, int64_t n, int subsample, bool input_sorted)
 {
     const uint64_t T = (uint64_t)ctx->T;
-    return !subsample && ctx->scan_dp && ctx->scan_method < 0 && ctx->scan_wg == 4 && !ctx->count_invariant &&
+    return !subsample && ctx->scan_dp && ctx->scan_f4 <= 0 && ctx->scan_method < 0 && ctx->scan_wg == 4 && !ctx->count_invariant &&
            !ctx->share_c && !ctx->scan_pair && ctx->waves_per_cu == 0 && (ctx->order || input_sorted) &&
            n >= ctx->dp_min_quartets && n >= 2 && n <= 0x7FFFFFFF && T * T * T <= 0xFFFFFFFFull &&
            T * (uint64_t)ctx->Sp < 0xFFFF0000ull;
@@ -624,6 +627,27 @@ int launch_scan_n(tq_ctx *ctx, const uint32_t *dq, const uint32_t *order, int64_
         if (subsample)
             return m ? launch_scan_wg2<true, 1, 4>(ctx, dq, order, Q, stream) : launch_scan_wg2<true, 0, 4>(ctx, dq, order, Q, stream);
         return m ? launch_scan_wg2<false, 1, 4>(ctx, dq, order, Q, stream) : launch_scan_wg2<false, 0, 4>(ctx, dq, order, Q, stream);
+    }
+    // row f4 as written (option scan_f4): own rows as 12-byte plane records only, pattern bits pulled out in the walk
+    const bool f4 = ctx->scan_f4 < 0 ? (subsample != 0 && ctx->scan_method < 0 && ctx->park_t) : ctx->scan_f4 != 0;
+    if (f4 && (ctx->scan_wg == 4 || ctx->scan_wg == 8 || ctx->scan_wg == 2) && Q >= ctx->wg_min_quartets && !ctx->count_invariant &&
+        !ctx->share_c && !ctx->scan_pair && ctx->waves_per_cu == 0 && (ctx->scan_method < 0 || ctx->scan_method == 1) &&
+        (uint64_t)ctx->T * (uint64_t)ctx->Sp < 0xFFFF0000ull) {
+        const int nw = ctx->scan_wg;
+        const int64_t nblk = (Q + nw - 1) / nw;
+        int64_t grid = nblk, xcd_chunk = 0;
+        if (ctx->xcd_remap && nblk >= 64) {
+            xcd_chunk = (nblk + 7) / 8;
+            grid = xcd_chunk * 8;
+        }
+#define TQ_F4_CASE(SUBF, NWF)                                                                                         \
+        if ((subsample != 0) == SUBF && nw == NWF)                                                                    \
+            hipLaunchKernelGGL((tq_scan_f4_kernel<SUBF, NWF>), dim3((unsigned)grid), dim3(NWF * WAVE), 0, stream,      \
+                               dev_data(ctx), dq, order, Q, ctx->d_cm, xcd_chunk);
+        TQ_F4_CASE(true, 4) TQ_F4_CASE(false, 4) TQ_F4_CASE(true, 8) TQ_F4_CASE(false, 8) TQ_F4_CASE(true, 2) TQ_F4_CASE(false, 2)
+#undef TQ_F4_CASE
+        TQ_HIP(ctx, hipGetLastError());
+        return TQ_OK;
     }
     // bank-private counters (option scan_method = 6, an A/B form: conflict-free atomics, but an LDS atomic costs its 4
     // cycles of operand transfer either way and the 64 KiB of counters leave two workgroups per CU -- measured slower,
@@ -1523,6 +1547,11 @@ int tq_set_option(tq_ctx *ctx, const char *name, int64_t value)
     }
     if (!strcmp(name, "scan_pair")) {
         ctx->scan_pair = value != 0;
+        return TQ_OK;
+    }
+    if (!strcmp(name, "scan_f4")) {
+        if (value < -1 || value > 1) return fail(ctx, TQ_ERR_INVALID_ARG, "scan_f4 must be -1 (subsample mode only), 0 or 1");
+        ctx->scan_f4 = (int)value;
         return TQ_OK;
     }
     if (!strcmp(name, "scan_dp")) {

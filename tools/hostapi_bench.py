@@ -9,6 +9,8 @@ tmparr,tmpmap=synth.simulate_tmparr(T,S,103)
 Q=1_000_000
 q=synth.random_quartets(T,Q,4242)
 eng=QuartetEngine(0); eng.set_data(tmparr,tmpmap)
+for kv in sys.argv[1:]:                  # engine options: name=value
+    k,v=kv.split("="); eng.set_option(k,int(v)); print("option",k,v)
 # host-buffer API (tq_resolve): quartets H2D + kernels + rows D2H, synchronous.  A chunked
 # 3-stage pipeline with pinned staging was tried and was 5-10 % SLOWER at every chunk size
 # (smaller launches + the extra host copy cost more than the overlap gains), so it was dropped.

@@ -16,7 +16,7 @@ import json
 from collections import defaultdict
 from pathlib import Path
 
-KERNELS = {"tq_scan_wg_kernel": "tq_scan_wg", "tq_scan_dp_kernel": "tq_scan_dp", "tq_bidiag_kernel": "tq_bidiag",
+KERNELS = {"tq_scan_wg_kernel": "tq_scan_wg", "tq_scan_f4_kernel": "tq_scan_f4", "tq_scan_dp_kernel": "tq_scan_dp", "tq_bidiag_kernel": "tq_bidiag",
            "tq_bdsqr_kernel": "tq_bdsqr", "tq_score_kernel": "tq_score"}
 
 

@@ -19,7 +19,7 @@ import sys
 from collections import defaultdict
 from pathlib import Path
 
-GROUPS = ("tq_prepare", "tq_key", "tq_dp_", "tq_scan_wg", "tq_scan_dp", "tq_scan_kernel", "tq_bidiag", "tq_bdsqr", "tq_score", "tq_svd",
+GROUPS = ("tq_prepare", "tq_key", "tq_dp_", "tq_scan_wg", "tq_scan_f4", "tq_scan_dp", "tq_scan_kernel", "tq_bidiag", "tq_bdsqr", "tq_score", "tq_svd",
           "rocprim")
 
 
@@ -60,8 +60,9 @@ def main():
     ft, fc, ff = collect(args.fetch_dir, "FETCH_SIZE")
     wt, wc, wf = collect(args.write_dir, "WRITE_SIZE")
     if not args.passes:
-        args.passes = fc.get("tq_scan_wg", 0) or fc.get("tq_scan_dp", 0) or fc.get("tq_scan_kernel", 0)
-        if args.passes != (wc.get("tq_scan_wg", 0) or wc.get("tq_scan_dp", 0) or wc.get("tq_scan_kernel", 0)):
+        scans = ("tq_scan_f4", "tq_scan_wg", "tq_scan_dp", "tq_scan_kernel")
+        args.passes = next((fc[g] for g in scans if fc.get(g)), 0)
+        if args.passes != next((wc[g] for g in scans if wc.get(g)), 0):
             sys.exit("the two runs made different numbers of passes")
     hot = [g for g in ft if g.startswith("tq_") and g != "tq_prepare"] + ["rocprim"]
     fetch_kb = sum(ft.get(g, 0.0) for g in hot) / args.passes

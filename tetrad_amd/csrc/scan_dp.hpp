@@ -112,7 +112,15 @@ __global__ void tq_dp_units_kernel(const uint32_t *__restrict__ keys, const uint
 }
 
 // ---- the scan -------------------------------------------------------------------------------------------------------
+#ifndef TQ_DP_OWN_AB
+#define TQ_DP_OWN_AB 1       // 1: every wave loads the nibble codes of rows a, b itself (two more vector loads per unit-step, L1 hits
+                             // for three of the four waves) and the shared image carries the combined plane record only: the
+                             // kernel is bound by LDS instructions (79 % busy against 37 % of the vector peak and 54 % of the
+                             // load path), and the pattern-partial panels were two 16-byte image reads per wave-step + two
+                             // stores per workgroup-step.  0: the panels come through the image as in tq_scan_wg_kernel (A/B)
+#endif
 struct DpOwn {
+    u32x4 a, b;              // nibble codes of rows a, b (TQ_DP_OWN_AB)
     u32x4 c, d1, d2;         // nibble codes of row c (0..3) and of rows d1, d2 (0..3, 4 = missing: the nib5 copy)
     u32x3 pc, pd1, pd2;      // plane records {miss, p0, p1}
 };
@@ -123,7 +131,7 @@ tq_scan_dp_kernel(DevData d, const uint32_t *__restrict__ quartets, const uint2 
                   const uint32_t *__restrict__ nunits_dev, uint32_t *__restrict__ cm)
 {
     static_assert(NW >= 2 && NW <= 8, "waves per workgroup");
-    __shared__ uint4 shared_ab[2][DP_SLOTS];
+    __shared__ uint4 shared_ab[2][TQ_DP_OWN_AB ? 64 : DP_SLOTS];
     __shared__ __attribute__((aligned(256))) uint32_t hist_all[NW][DP_HIST_DW];
     const int tid = threadIdx.x;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -145,7 +153,8 @@ tq_scan_dp_kernel(DevData d, const uint32_t *__restrict__ quartets, const uint2 
     // the wave's histogram starts on a 256-byte boundary: its base goes into the high byte of every site's field
     const uint32_t hbase = __builtin_amdgcn_readfirstlane(lds_offset(hist));
     const uint32_t B4 = (hbase >> 8) * 0x01010101u;
-    constexpr int NJOB = 2;
+    constexpr int NJOB = TQ_DP_OWN_AB ? 1 : 2, PJOB = NJOB - 1;          // PJOB: the job that fetches the plane records of a, b
+    constexpr int R1_SLOT = TQ_DP_OWN_AB ? 0 : 128;
     __syncthreads();
 
     for (int64_t blk0 = blockIdx.x; blk0 < 8 * xcd_chunk; blk0 += gridDim.x) {
@@ -183,31 +192,36 @@ tq_scan_dp_kernel(DevData d, const uint32_t *__restrict__ quartets, const uint2 
         const uint32_t force_miss = two ? 0u : 0xFFFFFFFFu, force_code = two ? 0u : 0x44444444u, keep2 = ~force_miss;
         const uint32_t l16 = (uint32_t)lane * 16u, l12 = (uint32_t)lane * 12u;
         const uint32_t oc = qc * npitch + l16, od1 = qd1 * npitch + l16, od2 = qdd2 * npitch + l16;
+        const uint32_t oa = (work ? q[0] : 0) * npitch + l16, ob = (work ? q[1] : 0) * npitch + l16;
         const uint32_t opc = qc * w3pitch + l12, opd1 = qd1 * w3pitch + l12, opd2 = qdd2 * w3pitch + l12;
         auto fetch_x = [=](int job, int tile) -> uint4 {
-            if (job == 0) return ld16(nib, la * npitch + l16 + (uint32_t)tile * (TILE / 2));
-            if (job == 1) return ld16(planes, la * wpitch + l16 + (uint32_t)tile * (WAVE * 16));
+            if (!TQ_DP_OWN_AB && job == 0) return ld16(nib, la * npitch + l16 + (uint32_t)tile * (TILE / 2));
+            if (job == PJOB) return ld16(planes, la * wpitch + l16 + (uint32_t)tile * (WAVE * 16));
             return make_uint4(0, 0, 0, 0);
         };
         auto fetch_y = [=](int job, int tile) -> uint4 {
-            if (job == 0) return ld16(nib, lb * npitch + l16 + (uint32_t)tile * (TILE / 2));
-            if (job == 1) return ld16(planes, lb * wpitch + l16 + (uint32_t)tile * (WAVE * 16));
+            if (!TQ_DP_OWN_AB && job == 0) return ld16(nib, lb * npitch + l16 + (uint32_t)tile * (TILE / 2));
+            if (job == PJOB) return ld16(planes, lb * wpitch + l16 + (uint32_t)tile * (WAVE * 16));
             return make_uint4(0, 0, 0, 0);
         };
         // image of one step (scan.hpp): panels 0-63 / 64-127 = ((a<<2)+b)<<4 per site byte, 128-191 = {p0a, p1a, Ma|Mb,
         // (p0a^p0b)|(p1a^p1b)}
         auto publish = [=](uint4 *buf, int job, uint4 x, uint4 y) {
-            if (job == 0) {
+            if (!TQ_DP_OWN_AB && job == 0) {
                 const uint32_t h = 0xF0F0F0F0u;
                 const uint32_t s0 = (x.x << 2) + y.x, s1 = (x.y << 2) + y.y, s2 = (x.z << 2) + y.z, s3 = (x.w << 2) + y.w;
                 buf[lane] = make_uint4((s0 << 4) & h, s0 & h, (s1 << 4) & h, s1 & h);
                 buf[64 + lane] = make_uint4((s2 << 4) & h, s2 & h, (s3 << 4) & h, s3 & h);
-            } else if (job == 1) {
-                buf[128 + lane] = make_uint4(x.y, x.z, x.x | y.x, (x.y ^ y.y) | (x.z ^ y.z));
+            } else if (job == PJOB) {
+                buf[R1_SLOT + lane] = make_uint4(x.y, x.z, x.x | y.x, (x.y ^ y.y) | (x.z ^ y.z));
             }
         };
         auto load_mine = [=](DpOwn &r, int tile) {
             const uint32_t tn = (uint32_t)tile * (TILE / 2), tp = (uint32_t)tile * (WAVE * 12);
+            if (TQ_DP_OWN_AB) {
+                r.a = ldv16(nib, oa + tn);
+                r.b = ldv16(nib, ob + tn);
+            }
             r.c = ldv16(nib, oc + tn);
             r.d1 = ldv16(nib5, od1 + tn);
             r.d2 = ldv16(nib5, od2 + tn);
@@ -233,21 +247,32 @@ tq_scan_dp_kernel(DevData d, const uint32_t *__restrict__ quartets, const uint2 
                 uint4 ab0, ab1, r1;
                 if (FAST || shares) {
                     const uint4 *buf = shared_ab[t & 1];
-                    ab0 = buf[lane];
-                    ab1 = buf[64 + lane];
-                    r1 = buf[128 + lane];
+                    if (!TQ_DP_OWN_AB) {
+                        ab0 = buf[lane];
+                        ab1 = buf[64 + lane];
+                    }
+                    r1 = buf[R1_SLOT + lane];
                 } else {                                        // group boundary: private rows a and b
-                    const uint32_t o0 = q[0] * pitch + (uint32_t)t * TILE + l16;
-                    const uint32_t o1 = q[1] * pitch + (uint32_t)t * TILE + l16;
-                    const uint4 a0 = ld16(rows, o0), a1 = ld16(rows, o0 + 1024u);
-                    const uint4 b0 = ld16(rows, o1), b1 = ld16(rows, o1 + 1024u);
-                    ab0 = make_uint4(((a0.x << 2) + b0.x) << 4, ((a0.y << 2) + b0.y) << 4, ((a0.z << 2) + b0.z) << 4,
-                                     ((a0.w << 2) + b0.w) << 4);
-                    ab1 = make_uint4(((a1.x << 2) + b1.x) << 4, ((a1.y << 2) + b1.y) << 4, ((a1.z << 2) + b1.z) << 4,
-                                     ((a1.w << 2) + b1.w) << 4);
+                    if (!TQ_DP_OWN_AB) {
+                        const uint32_t o0 = q[0] * pitch + (uint32_t)t * TILE + l16;
+                        const uint32_t o1 = q[1] * pitch + (uint32_t)t * TILE + l16;
+                        const uint4 a0 = ld16(rows, o0), a1 = ld16(rows, o0 + 1024u);
+                        const uint4 b0 = ld16(rows, o1), b1 = ld16(rows, o1 + 1024u);
+                        ab0 = make_uint4(((a0.x << 2) + b0.x) << 4, ((a0.y << 2) + b0.y) << 4, ((a0.z << 2) + b0.z) << 4,
+                                         ((a0.w << 2) + b0.w) << 4);
+                        ab1 = make_uint4(((a1.x << 2) + b1.x) << 4, ((a1.y << 2) + b1.y) << 4, ((a1.z << 2) + b1.z) << 4,
+                                         ((a1.w << 2) + b1.w) << 4);
+                    }
                     const uint4 pa = ld16(planes, q[0] * wpitch + (uint32_t)t * (WAVE * 16) + l16);
                     const uint4 pb = ld16(planes, q[1] * wpitch + (uint32_t)t * (WAVE * 16) + l16);
                     r1 = make_uint4(pa.y, pa.z, pa.x | pb.x, (pa.y ^ pb.y) | (pa.z ^ pb.z));
+                }
+                if (TQ_DP_OWN_AB) {                             // ((a<<2)+b)<<4 per site byte from the wave's own nibble words
+                    const uint32_t h = 0xF0F0F0F0u;
+                    const uint32_t s0 = (own.a.x << 2) + own.b.x, s1 = (own.a.y << 2) + own.b.y, s2 = (own.a.z << 2) + own.b.z,
+                                   s3 = (own.a.w << 2) + own.b.w;
+                    ab0 = make_uint4((s0 << 4) & h, s0 & h, (s1 << 4) & h, s1 & h);
+                    ab1 = make_uint4((s2 << 4) & h, s2 & h, (s3 << 4) & h, s3 & h);
                 }
                 // sites that get an atomic: a, b, c present and, for at least one of the two quartets, d present and the
                 // four bases not all equal (the second condition only saves atomics: invariant bins are zeroed at the end)

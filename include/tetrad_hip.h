@@ -227,7 +227,10 @@ int tq_timing_read_kernels(tq_ctx *ctx, double *ms, int n_ms, int64_t *calls);
  * scan_dp (1, default: full-mode batches -- subsample = 0 -- of at least dp_min_quartets go to the joint-histogram scan,
  * scan_dp.hpp: two quartets that share their first three taxa per wavefront, one LDS atomic per site and pair; the same rows,
  * bit for bit; 0: always one quartet per wavefront), dp_min_quartets (default 32 768; smaller batches are not sorted and hold
- * few pairs).                                                                                                        */
+ * few pairs), scan_f4 (-1, default: in subsample mode the cooperative scan streams a wavefront's own rows as 12-byte
+ * {missing, bit 0, bit 1} records only and makes the pattern of a counted site inside the histogram walk, scan_f4.hpp =
+ * SURVEY 8 row f4; 1: in full mode too (slower there); 0: the nibble-code kernel of rounds 1-3 everywhere; NOTE: 0 is a value
+ * of its own for this option, the default is -1).                                                                   */
 int tq_set_option(tq_ctx *ctx, const char *name, int64_t value);
 
 /* Test hook: copy the scratch of the last resolve call to the host.  which = 0: count slab

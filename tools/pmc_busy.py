@@ -4,9 +4,13 @@ as profiles/pmc_busy_latest.json -- bench.py quotes them per kernel in roofline.
 
     python tools/pmc_busy.py DIR [DIR ...] --out profiles/pmc_busy_latest.json --source profiles/r02_.../ --commit abc123
 
-Definitions (per dispatch averages; SQ_ACTIVE_INST_* and SQ_BUSY_CU_CYCLES count quad-cycles summed over the chip):
-  valu_busy      = SQ_ACTIVE_INST_VALU / SQ_BUSY_CU_CYCLES        (share of CU-busy time with a VALU instruction executing,
-                                                                   the 4 SIMDs of a CU counted together, as in r01's summaries)
+Definitions (per dispatch averages, summed over the chip):
+  valu_inst_per_cu_cycle = SQ_INSTS_VALU / SQ_BUSY_CU_CYCLES      vector wave-instructions per CU-busy cycle.  A wave64 instruction on
+                                                                   32-bit operands issues over 2 cycles of its SIMD (32 lanes per cycle,
+                                                                   MI355X_MICROARCH.md), an f64 one over 4: a CU's 4 SIMDs take at most 2
+                                                                   (1 for f64) per cycle
+  valu_busy      = valu_inst_per_cu_cycle / that peak             (rounds 1-3 divided by 1 for every kernel, which made the integer scan
+                                                                   kernels look twice as VALU-busy as they are: 0.76 was 0.38)
   lds_busy       = SQ_LDS_IDX_ACTIVE / SQ_BUSY_CU_CYCLES
   lds_conflict   = SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE
 """
@@ -44,8 +48,12 @@ def main():
         e = {"counters_per_dispatch": {n: round(v, 1) for n, v in sorted(m.items())}}
         busy = m.get("SQ_BUSY_CU_CYCLES")
         if busy:
-            if "SQ_ACTIVE_INST_VALU" in m:
-                e["valu_busy"] = round(m["SQ_ACTIVE_INST_VALU"] / busy, 4)
+            nv = m.get("SQ_INSTS_VALU", m.get("SQ_ACTIVE_INST_VALU"))
+            if nv is not None:
+                peak = 2.0 if k.startswith("tq_scan") else 1.0          # 32-bit integer work / f64 work
+                e["valu_inst_per_cu_cycle"] = round(nv / busy, 4)
+                e["valu_peak_inst_per_cu_cycle"] = peak
+                e["valu_busy"] = round(nv / busy / peak, 4)
             if "SQ_LDS_IDX_ACTIVE" in m:
                 e["lds_busy"] = round(m["SQ_LDS_IDX_ACTIVE"] / busy, 4)
             if "TA_TA_BUSY_sum" in m:       # texture-address path: every vector memory instruction passes it (tools/probe_ta.hip)

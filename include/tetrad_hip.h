@@ -208,7 +208,7 @@ int tq_timing_read_split(tq_ctx *ctx, double *total_ms, double *scan_ms, double 
 int tq_timing_read_kernels(tq_ctx *ctx, double *ms, int n_ms, int64_t *calls);
 
 /* Tuning / diagnostic knobs (value 0 = library default unless noted).  Returns TQ_OK or an error.
- * Names: nrep, waves_per_cu, wg_min_quartets (batches below it -- default 2048 -- are scanned by the one-wave-per-quartet kernel:
+ * Names: nrep, waves_per_cu, wg_min_quartets (batches below it -- default 4096 -- are scanned by the one-wave-per-quartet kernel:
  * small calls are latency-bound), batch (quartets per internal batch, default 2^23; device scratch is about
  * 3.2 KB per quartet of the largest batch resolved so far), order, scan_wg (waves per scan workgroup: 1, 2, 4, 8, 16), scan_method (-1 auto), svd_method (0 Jacobi,
  * 1 Householder+QR), bidiag_layout (1, default: the bidiagonalisation deals a matrix 2 x 2 over four lanes; 0: four column

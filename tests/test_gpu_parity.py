@@ -21,7 +21,7 @@ ATOL_REL_SMAX = 1e-12
 def engine(request):
     """Every parity test runs against both device SVD paths: Householder + bidiagonal QR
     (default) and one-sided Jacobi -- and against both scan kernels: the "hqr" engine sends every batch of 64 quartets or
-    more to the cooperative workgroup kernels (the default threshold is 2 048: smaller calls are latency-bound and go to the
+    more to the cooperative workgroup kernels (the default threshold is 4 096: smaller calls are latency-bound and go to the
     one-wave-per-quartet kernel) -- subsample mode to the plane-record scan (scan_f4.hpp), full mode to the joint-histogram scan
     (scan_dp.hpp) -- the "jacobi" engine keeps the defaults, so the small golden cases cover the one-wave kernel, and the third
     engine runs the cooperative kernel of rounds 1-3 in both modes."""

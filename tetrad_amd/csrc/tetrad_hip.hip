@@ -129,10 +129,11 @@ struct tq_ctx {
     uint64_t *d_bdsqr_stats = nullptr;   // diagnostics (option "bdsqr_stats"): {matrices, rotation steps of all lanes,
                                          // lane-slots issued (64 x wave iterations), sweeps} summed over the launches
     int scan_wg = 4;                // waves per workgroup of the cooperative scan kernel (1 = one wave per quartet)
-    int64_t wg_min_quartets = 2048; // smaller batches go to the one-wave-per-quartet kernel: a call of a thousand quartets does not
+    int64_t wg_min_quartets = 4096; // smaller batches go to the one-wave-per-quartet kernel: a call of a few thousand quartets does not
                                     // fill the chip and is bound by the latency of one quartet's 25 dependent steps, which the
-                                    // cooperative kernel's per-step barrier and image hand-over only lengthen (1 000 random
-                                    // quartets 0.179 -> 0.163 ms per call; the cooperative kernel wins from ~8 000 on)
+                                    // cooperative kernels' per-step barrier and image hand-over only lengthen (1 000 random
+                                    // quartets 0.185 -> 0.164 ms per call, 3 000: 0.198 -> 0.191; the cooperative kernels win from
+                                    // ~4 000 on: tools/experiments/wg_min_threshold.py)
     int xcd_remap = 1;              // 1: scan workgroups of one XCD take a contiguous part of the sorted order
     int count_invariant = 0;        // 1: invariant sites (all four bases equal, none missing) are counted as well -- what the reference's
                                     // count kernels do when their caller's mask leaves such a site open (resolve_quartets.py:59-64);
@@ -1566,7 +1567,7 @@ int tq_set_option(tq_ctx *ctx, const char *name, int64_t value)
     }
     if (!strcmp(name, "wg_min_quartets")) {
         if (value < 0) return fail(ctx, TQ_ERR_INVALID_ARG, "wg_min_quartets must be >= 0");
-        ctx->wg_min_quartets = value ? value : 2048;
+        ctx->wg_min_quartets = value ? value : 4096;
         return TQ_OK;
     }
     if (!strcmp(name, "bidiag_layout")) {

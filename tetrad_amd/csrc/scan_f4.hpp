@@ -184,12 +184,14 @@ tq_scan_f4_kernel(DevData d, const uint32_t *__restrict__ quartets, const uint32
             publish(0, job, sx, sy);
             uint32_t tile_carry = 0;
             __syncthreads();
-            for (int t = 0; t < d.ntiles; ++t) {
+            // one step on the plane records (cpc, cpd); those of step t+1 go into (npc, npd) at its top -- the walk reads
+            // the current ones -- and the loop below alternates the two register pairs (unrolled by two: no copies)
+            auto one_step = [&](const u32x3 &cpc, const u32x3 &cpd, u32x3 &npc, u32x3 &npd, int t) {
                 const int tn = min(t + 1, last);
                 sx = fetch_x(job, tn);
                 sy = fetch_y(job, tn);
-                // the plane records of step t+1 into a second register pair: the walk reads the current ones
-                const u32x3 npc = ldv12(planes3, opc + (uint32_t)tn * (WAVE * 12)), npd = ldv12(planes3, opd + (uint32_t)tn * (WAVE * 12));
+                npc = ldv12(planes3, opc + (uint32_t)tn * (WAVE * 12));
+                npd = ldv12(planes3, opd + (uint32_t)tn * (WAVE * 12));
                 __builtin_amdgcn_sched_barrier(0);
                 if (FAST || work) {
                     uint4 r1;
@@ -214,18 +216,22 @@ tq_scan_f4_kernel(DevData d, const uint32_t *__restrict__ quartets, const uint32
                         Bw = pa.w;
                         img = reinterpret_cast<const uint8_t *>(own_ab[w] + lane);
                     }
-                    const uint32_t C = count_mask_shared<SUB>(r1, Bw, pc, pd, lane, tile_carry);
-                    walk_planes(C, pc.y, pc.z, pd.y, pd.z, img, hist);
+                    const uint32_t C = count_mask_shared<SUB>(r1, Bw, cpc, cpd, lane, tile_carry);
+                    walk_planes(C, cpc.y, cpc.z, cpd.y, cpd.z, img, hist);
                 }
                 __builtin_amdgcn_sched_barrier(0);
-                pc = npc;
-                pd = npd;
                 if (job < NJOB) {
                     pin4(sx);
                     pin4(sy);
                 }
                 publish((t + 1) & 1, job, sx, sy);
                 __syncthreads();
+            };
+            u32x3 qc_, qd_;
+            for (int t = 0; t < d.ntiles; t += 2) {
+                one_step(pc, pd, qc_, qd_, t);
+                if (t + 1 >= d.ntiles) break;
+                one_step(qc_, qd_, pc, pd, t + 1);
             }
         };
         {

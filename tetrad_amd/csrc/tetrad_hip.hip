@@ -13,12 +13,18 @@
 //   rows    u8   [T][Sp]   base code 0..3 per site, missing/pad -> 0  (Sp = S rounded up to 2048;
 //                          inside each 2048-site step the bytes sit in two 1 KiB panels, row_offset())
 //   nib     u8   [T][Sp/2] the same codes, two per byte (nib_offset())
+//   nib5    u8   [T][Sp/2] the same with 4 for a missing cell (rows d1, d2 of the joint-histogram scan)
 //   planes  u32x4[T][W]    per 32 sites: {missing bits, base bit 0, base bit 1, run-begin bits}, W = Sp/32
 //   planes3 u32x3[T][W]    compact copy {missing, bit 0, bit 1}; runbeg u32 [W] run-begin bits, stored once
 //
 // Kernels (each in its own header of this directory, all included below into one translation unit):
 //   prepare.hpp   layout build, lexicographic unranking, sort keys
-//   scan.hpp      tq_scan_wg_kernel / tq_scan_kernel: site scan -> 256 pattern counts per quartet
+//   scan.hpp      tq_scan_wg_kernel / tq_scan_kernel: site scan -> 256 pattern counts per quartet (nibble codes + plane
+//                 records; the one-wave-per-quartet kernel of small calls)
+//   scan_f4.hpp   tq_scan_f4_kernel: the cooperative scan on 12-byte plane records only (default of subsample mode)
+//   scan_dp.hpp   tq_scan_dp_kernel: two quartets that share three taxa per wave, one joint histogram (default of full mode
+//                 from 32 768 quartets on); unit list from the sorted order
+//   scan_pb.hpp   tq_scan_pb_kernel: bank-private counters (A/B form)
 //   hqr.hpp       tq_bidiag_kernel + tq_bdsqr_kernel + tq_score_kernel: singular values (default)
 //   jacobi.hpp    tq_svd_kernel: one-sided Jacobi singular values in registers (alternative)
 //   bootstrap.hpp tq_boot_*: bootstrap replicate built on the device

@@ -24,7 +24,11 @@ def timeit(f, n=10):
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(n): f()
     torch.cuda.synchronize(); return (time.perf_counter() - t0) / n * 1e3
-for sub in (True, False):
+pads = [int(a) for a in sys.argv[1:]] or [0]
+for sub, pad in [(True, p) for p in pads] + [(False, 0)]:
+    if pad:            # (needs a build with the experiment's `scan_pad_lds` option: unused dynamic LDS on the scan's launch, i.e.
+        e1.set_option("scan_pad_lds", pad); e2.set_option("scan_pad_lds", pad)      # fewer scan workgroups per CU; not in the product)
+    print(f"-- scan_pad_lds {pad}")
     def one():
         e1.resolve_dev(d_q.data_ptr(), Q, sub, oa[0].data_ptr(), oa[1].data_ptr(), oa[2].data_ptr(), s1.cuda_stream)
     print(f"sub={sub} one engine, 1e6 quartets: {timeit(one):.3f} ms", flush=True)

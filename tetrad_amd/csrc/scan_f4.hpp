@@ -9,10 +9,15 @@
 // records ONLY (3 vector loads per wave-step instead of 5), nothing is parked, and the set-bit walk makes the pattern
 // of a COUNTED site (5.6 of a lane's 32 in subsample mode) itself -- the (a,b) byte straight from the workgroup's shared
 // image in LDS (one ds_read_u8, as the parked byte before), the (c,d) nibble by four v_bfe_u32 on the plane words it holds.
-// Per wave-step that is 3 loads, no park stores and two image reads fewer -- and 16 vector instructions per walk trip
-// instead of 6.  MEASURED SLOWER (profiles/r04_scan/README.md section 9): the kernel trades LDS
-// instructions and loads, which it has to spare after the change, for vector instructions, which it has not.  Option
-// "scan_f4", off by default, parity-tested (tests/test_gpu_configs.py) and a fuzz option.
+// Per wave-step that is 3 loads, no park stores and two image reads fewer -- and 15 vector instructions per walk trip
+// instead of 6.  That trade pays: the scan of rounds 1-3 was bound by its LDS instructions with vector issue at 38 % of
+// the CU's 2-wave-instructions-per-cycle peak (it had been read as 76 % of a peak of 1).  MEASURED (DESIGN.md section 4.1,
+// profiles/r04_scan/README.md section 9): LDS instructions -28 %, LDS-array cycles -22 %, c3 subsample scan 5.63 -> 5.32 ms,
+// c2 -7 %, c4 -8 % -- once the image's pattern partial is TRANSPOSED ([dword j][lane]: the walk's byte reads are then
+// conflict-free; with the lane-contiguous panels of tq_scan_wg_kernel they cost 600 M conflict cycles per dispatch and
+// the whole gain).  Default of subsample mode (option "scan_f4" = -1); in full mode the walk has 19 trips per step and the
+// form loses against the slot kernels (scan_f4 = 1 selects it there too); parity-tested (tests/test_gpu_configs.py, the
+// "hqr" engine of tests/test_gpu_parity.py) and a fuzz option.
 #pragma once
 
 // set-bit walk on plane words: for every set bit i of c, hist[abbyte(i) | cd(i)] += 1.  abbyte = (a<<6|b<<4) of site i, read
